@@ -1,0 +1,228 @@
+/*
+ * yolo_hip.h -- C ABI of libyolo_hip.so, the MI355X (gfx950) implementation of the YOLOv1 hot path.
+ *
+ * The reference (mattiaskvist/yolo-v1) is pure Python with no FFI layer; its hot path is the
+ * arithmetic behind the `src/yolo` module surface.  This header is the boundary a
+ * maintainer binds instead of the torch ops those modules call: every entry point names the
+ * reference lines it replaces.  INTEGRATION.md shows the ctypes binding.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes, no torch types.  All pointers are DEVICE pointers
+ *     unless a parameter is called host_*.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream).  Calls only enqueue
+ *     work; nothing here synchronises, allocates or frees device memory, so every call can be
+ *     captured in a hipGraph.  Workspaces are caller-allocated.
+ *   - return value: 0 = ok, <0 = YOLO_E_* argument error, >0 = hipError_t.  No exceptions cross
+ *     the ABI.  yolo_hip_last_error() gives a human-readable string for the calling thread.
+ *   - activations inside the network are "padded NHWC bf16": [N][H+2*halo][W+2*halo][C] with a
+ *     zero border of `halo` pixels that producers never write (so 3x3/pad-1 consumers need no
+ *     bounds checks).  The caller zeroes a buffer once at allocation.
+ */
+#ifndef YOLO_HIP_H
+#define YOLO_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define YOLO_HIP_ABI_VERSION 1
+
+#define YOLO_E_ARG (-1)         /* bad argument (null pointer, size out of range)              */
+#define YOLO_E_UNSUPPORTED (-2) /* shape not supported by the kernels (see each function)      */
+
+typedef void *yolo_stream_t;
+
+int yolo_hip_abi_version(void);
+const char *yolo_hip_last_error(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * Post-processing: S x S x B box decode, pairwise IoU, per-image NMS.  fp64 arithmetic on fp32
+ * inputs in the reference's operation order -> bit-exact records, class ids and kept indices.
+ * ------------------------------------------------------------------------------------------- */
+
+/* Replaces YOLOInference.parse_predictions (src/yolo/inference.py:170-210) and
+ * mAPMetric._parse_predictions (src/yolo/metrics.py:185-218) for a whole batch.
+ *   pred    [N][S][S][5B+C] fp32
+ *   rec     [N][S*S*B][6] f64 = {class_id, conf*prob, x, y, w, h}; per image the first counts[n]
+ *           rows are valid, in (row i, col j, box b) scan order
+ *   counts  [N] int32
+ * Limits: S*S*B <= 1024, B <= 8. */
+int yolo_decode(const float *pred, int N, int S, int B, int C, double conf_thr,
+                double *rec, int32_t *counts, yolo_stream_t stream);
+
+/* Replaces mAPMetric._parse_ground_truth (src/yolo/metrics.py:232-256).
+ *   rec [N][S*S][5] f64 = {class_id, x, y, w, h}; counts [N]. */
+int yolo_decode_gt(const float *tgt, int N, int S, int B, int C,
+                   double *rec, int32_t *counts, yolo_stream_t stream);
+
+#define YOLO_NMS_INFERENCE 0 /* inference.py:212-249,298-317: IoU has +1e-6, output in confidence order   */
+#define YOLO_NMS_METRICS 1   /* metrics.py:258-341: union==0 -> 0, no eps, output grouped by class         */
+
+/* Replaces YOLOInference.non_max_suppression (src/yolo/inference.py:298-317, variant 0) and
+ * mAPMetric._apply_nms (src/yolo/metrics.py:270-296, variant 1), one wavefront per image (two boxes per lane).
+ *   rec [N][max_per_img][6] f64 as written by yolo_decode; counts [N]
+ *   keep [N][max_per_img] int32: indices into the image's records in the reference's OUTPUT order;
+ *   keep_counts [N].
+ * A later box survives a kept one iff class differs or IoU < thr (IoU == thr suppresses).
+ * Limit: max_per_img <= 128. */
+int yolo_nms(const double *rec, const int32_t *counts, int N, int max_per_img, double thr, int variant,
+             int32_t *keep, int32_t *keep_counts, yolo_stream_t stream);
+
+/* Pairwise IoU matrix out[na][nb] between boxes a[na][4], b[nb][4] (x,y,w,h f64); the scalar
+ * formulas of YOLOInference.iou (inference.py:229-249, variant 0) and mAPMetric._calculate_iou
+ * (metrics.py:313-341, variant 1). */
+int yolo_pairwise_iou(const double *a, int na, const double *b, int nb, int variant,
+                      double *out, yolo_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Loss.  Replaces YOLOLoss.forward + compute_iou (src/yolo/loss.py:87-212) AND its autograd
+ * backward in one pass: responsible-box selection by IoU, the five partial sums, dL/dpred
+ * including the gradient that flows through the (non-detached) IoU target.
+ *   pred,tgt [N][S][S][5B+C] fp32
+ *   out      [8] fp32 : {total, coord, conf_obj, conf_noobj, class} each already / N, then
+ *            out[5] = error flag (1.0 if some object cell selects a target slot >= B; the
+ *            reference raises IndexError there), out[6..7] unused
+ *   dpred    [N][S][S][5B+C] fp32 = d total / d pred, or NULL (forward only)
+ *   work     [8*N] f64 caller workspace (per-image partial sums; deterministic reduction order)
+ * Limits: B <= 8, S*S <= 1024. */
+int yolo_loss_fwd_bwd(const float *pred, const float *tgt, int N, int S, int B, int C,
+                      float lambda_coord, float lambda_noobj,
+                      float *out, float *dpred, double *work, yolo_stream_t stream);
+
+/* YOLOLoss.compute_iou (src/yolo/loss.py:174-212) for n box pairs, fp32. */
+int yolo_loss_iou(const float *boxes1, const float *boxes2, long n, float *out, yolo_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Network layers.  bf16 storage, fp32 MFMA accumulation.  These replace the aten kernels behind
+ * nn.Conv2d + nn.LeakyReLU(0.1), nn.MaxPool2d(2,2), nn.Linear as instantiated by
+ * YOLOv1Backbone (src/yolo/models.py:47-84), the FC head (models.py:239-245) and DetectionHead
+ * (models.py:313-332).
+ * ------------------------------------------------------------------------------------------- */
+
+/* One implicit-GEMM problem:  out[px][co] = epi( sum_{tap,c} in[row(px) + tapoff(tap) + c] * w[co][tap][c] )
+ * It covers conv forward, conv data-gradient (weights packed transposed+flipped), and Linear
+ * forward / data-gradient (a 1x1 conv on a 1x1 image).  All "elements" are bf16 elements. */
+typedef struct yolo_igemm_desc {
+    /* output pixel grid */
+    int32_t N, Ho, Wo;
+    /* input addressing: row(px=(n,oy,ox)) = n*in_img_stride + oy*in_row_stride*sy + ox*in_px_stride*sx ... */
+    int64_t in_img_stride;  /* elements between images of the (padded) input                       */
+    int32_t in_row_stride;  /* elements between input rows                                         */
+    int32_t in_px_stride;   /* elements between input pixels (= channel count of the buffer)       */
+    int32_t in_off;         /* element offset of (row 0, px 0, tap 0) inside an image              */
+    int32_t stride;         /* conv stride (1 or 2)                                                */
+    int32_t KH, KW;         /* taps                                                                */
+    int32_t tap_len;        /* contiguous input elements per tap (= Cin; multiple of BK)           */
+    int32_t Cout;           /* output channels (rows of w)                                         */
+    /* output addressing (padded NHWC): out[(n*out_img_stride) + (oy*out_row_stride) + ox*out_px_stride + out_off + co] */
+    int64_t out_img_stride;
+    int32_t out_row_stride, out_px_stride, out_off;
+    /* epilogue */
+    int32_t epilogue;       /* YOLO_EPI_*                                                          */
+    float slope;            /* LeakyReLU negative slope                                            */
+    int32_t out_fp32;       /* 1: out is fp32, 0: bf16                                             */
+    int32_t split_k;        /* >1: K split over blockIdx.y, fp32 atomicAdd into out (out_fp32=1,
+                               epilogue NONE; caller zero-fills out and applies bias afterwards)   */
+    /* aux addressing for YOLO_EPI_MUL_DLRELU (same form as the output addressing) */
+    int64_t aux_img_stride;
+    int32_t aux_row_stride, aux_px_stride, aux_off;
+} yolo_igemm_desc;
+
+#define YOLO_EPI_NONE 0        /* out = acc                                                        */
+#define YOLO_EPI_BIAS 1        /* out = acc + bias[co]                                             */
+#define YOLO_EPI_BIAS_LRELU 2  /* out = lrelu(acc + bias[co])            (Conv2d/Linear + LeakyReLU) */
+#define YOLO_EPI_MUL_DLRELU 3  /* out = acc * (aux[px][co] > 0 ? 1 : slope)  (dgrad through the
+                                  previous layer's LeakyReLU; aux = that layer's output, bf16,
+                                  addressed by the aux_* strides)                                                        */
+
+int yolo_igemm(const yolo_igemm_desc *d, const void *in_bf16, const void *w_bf16 /*[Cout][KH*KW*tap_len]*/,
+               const float *bias, const void *aux_bf16, void *out, yolo_stream_t stream);
+
+/* Weight-gradient of a conv / Linear, "flat" pixel indexing:
+ *     dw[co][tap][ci] (+)= sum_{p < P} dy[p*dy_px_stride + co] * x[p*x_px_stride + tapoff(tap) + ci]
+ *     tapoff(ky,kx) = (ky - pad)*x_row_stride + (kx - pad)*x_px_stride
+ * p runs over EVERY pixel slot of the zero-haloed dy buffer (halo slots hold zeros and add nothing),
+ * so dy and x must share one padded geometry (stride-1 convs; a stride-2 conv passes a zero-stuffed
+ * dy of the input's geometry).  x needs a guard band of finite values (zeros) of at least
+ * |tapoff| elements before and after the buffer.  dw is fp32 in the packed layout
+ * [Cout][KH*KW][Cin]; with split > 1 or accumulate != 0 it is accumulated with fp32 atomics
+ * (caller zero-fills / owns the previous value).  db[co] += sum_p dy[p][co] if db != NULL
+ * (always accumulated: caller zero-fills).  Replaces the weight / bias gradient of aten
+ * convolution_backward and addmm backward. */
+typedef struct yolo_wgrad_desc {
+    int64_t P;                       /* dy pixel slots                                            */
+    int32_t dy_px_stride, x_px_stride; /* elements between pixel slots (multiples of 8)           */
+    int32_t Cout, Cin;
+    int32_t KH, KW, pad;
+    int64_t x_row_stride;            /* elements between input rows (multiple of 8)               */
+    int32_t split;                   /* pixel-range split (>= 1)                                  */
+    int32_t accumulate;              /* 1: add into dw even when split == 1                       */
+} yolo_wgrad_desc;
+
+int yolo_wgrad(const yolo_wgrad_desc *d, const void *x_bf16, const void *dy_bf16,
+               float *dw_packed, float *db, yolo_stream_t stream);
+
+/* MaxPool2d(2,2) on padded NHWC bf16 (models.py:51,55,65,72) and its backward fused with the
+ * backward of the LeakyReLU that precedes the pool:
+ *   dz[n][y][x][c] = (y,x is the arg-max of its 2x2 window, first in scan order on ties)
+ *                    ? dpool[n][y/2][x/2][c] * (yfull > 0 ? 1 : slope) : 0 */
+typedef struct yolo_pool_desc {
+    int32_t N, H, W, C;       /* un-pooled logical size                                          */
+    int32_t in_halo, out_halo;
+} yolo_pool_desc;
+int yolo_maxpool2_fwd(const yolo_pool_desc *d, const void *x_bf16, void *y_bf16, yolo_stream_t stream);
+int yolo_maxpool2_bwd_lrelu(const yolo_pool_desc *d, const void *yfull_bf16, const void *dpool_bf16,
+                            float slope, void *dz_bf16, yolo_stream_t stream);
+
+/* ---- layout / precision conversion at the boundary to PyTorch-layout fp32 tensors ------------- */
+
+/* NCHW fp32 -> padded NHWC bf16 with Cpad >= C channels (extra channels zero). */
+int yolo_nchw_f32_to_nhwc_bf16(const float *x, int N, int C, int H, int W, void *y, int Cpad,
+                               int halo_lo, int halo_hi, yolo_stream_t stream);
+/* padded NHWC bf16 -> NCHW fp32 (module boundary, e.g. YOLOv1Backbone.forward's return value). */
+int yolo_nhwc_bf16_to_nchw_f32(const void *x, int N, int C, int H, int W, int halo, float *y, yolo_stream_t stream);
+/* padded NHWC bf16 -> NCHW bf16: nn.Flatten order (c*H*W + h*W + w) in front of the FC head
+ * (src/yolo/models.py:240), so that Linear weights keep their state_dict column order. */
+int yolo_nhwc_bf16_to_nchw_bf16(const void *x, int N, int C, int H, int W, int halo, void *y, yolo_stream_t stream);
+
+/* OIHW fp32 -> packed bf16 [Cout][KH][KWp][Cinp] (forward operand) and, if wt != NULL,
+ * [Cin][KH][KW][Cout] with taps flipped (data-gradient operand).  KWp/Cinp >= KW/Cin pad with zeros. */
+int yolo_pack_conv_weight(const float *w_oihw, int Cout, int Cin, int KH, int KW, int Cinp, int KWp,
+                          void *w_fwd_bf16, void *w_dgrad_bf16, yolo_stream_t stream);
+/* Linear weight [O][K] fp32 -> bf16 [O][K'] with the K axis permuted from (c, hw) to (hw, c) order
+ * (HW = 1: plain cast) and, if wt != NULL, the transposed copy [K'][O] for the data-gradient. */
+int yolo_pack_fc_weight(const float *w, int O, int C, int HW, void *w_fwd_bf16, void *w_t_bf16, yolo_stream_t stream);
+/* packed fp32 gradient [Cout][KH][KWp][Cinp] -> OIHW fp32 (accumulate=0: overwrite, 1: add). */
+int yolo_unpack_conv_wgrad(const float *dw_packed, int Cout, int Cin, int KH, int KW, int Cinp, int KWp,
+                           float *dw_oihw, int accumulate, yolo_stream_t stream);
+/* Row-segment unfold for the 7x7/stride-2 first layer's WEIGHT GRADIENT only (Cin=3 gives no
+ * channel-contiguous K axis): xcol[n][oy+h][ox+h][ky*seg + j] = x[n][oy*stride+ky][(ox*stride)*px + j],
+ * written in the zero-haloed geometry of the layer's output so that yolo_wgrad's flat indexing
+ * applies with one tap.  (models.py:49; the forward conv of that layer is im2col-free.) */
+int yolo_im2col_rows(const void *x_bf16, long x_img_stride, int x_row_stride, int x_px_stride, int stride,
+                     int KH, int seg, int N, int Ho, int Wo, int out_halo, void *xcol_bf16, yolo_stream_t stream);
+/* fp32 [R][Ccols] -> bf16 transposed y[c*ld + r] (ld >= R; columns R..ld-1 are not written: the
+ * caller zero-fills once).  Data-gradient operand of a Linear layer ([K][O] from [O][K]). */
+int yolo_transpose_f32_to_bf16(const float *x, int R, int Ccols, void *y_bf16, int ld, yolo_stream_t stream);
+int yolo_cast_f32_to_bf16(const float *x, long n, void *y_bf16, yolo_stream_t stream);
+int yolo_cast_bf16_to_f32(const void *x_bf16, long n, float *y, yolo_stream_t stream);
+/* y = lrelu(x + bias[col]) over [R][Ccols] fp32, bf16 and/or fp32 outputs (finishes a split-K Linear). */
+int yolo_bias_lrelu_rows(const float *x, const float *bias, int R, int Ccols, float slope,
+                         void *y_bf16, float *y_f32, yolo_stream_t stream);
+
+/* y[r][0..ld) = bf16( x[r][c] * (mask ? (mask[r][c] ? scale : 0) : 1) * (act ? (act[r][c] > 0 ? 1 : slope) : 1) ),
+ * columns Cc..ld-1 zero.  x fp32 [R][Cc], mask u8 [R][Cc], act bf16 [R][Cc].  Backward of
+ * Dropout(0.5) + LeakyReLU(0.1) of the FC head (models.py:242-243) and the fp32->bf16 hand-over of
+ * dL/dpred (row padding to a multiple of 8 columns). */
+int yolo_scale_rows_to_bf16(const float *x, const unsigned char *mask, float scale, const void *act_bf16, float slope,
+                            int R, int Cc, int ld, void *y_bf16, yolo_stream_t stream);
+/* nn.Dropout forward on bf16: y = mask ? x * scale : 0 (mask u8 drawn by the caller's RNG). */
+int yolo_dropout_bf16(const void *x_bf16, const unsigned char *mask, float scale, long n, void *y_bf16, yolo_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* YOLO_HIP_H */

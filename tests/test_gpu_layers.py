@@ -1,0 +1,179 @@
+"""GPU parity of the MFMA layer kernels (yolo_igemm / yolo_wgrad / pool / layout), driven through the
+same engine.Plan the models use, against (a) fixtures produced with stock torch ops (the reference's
+arithmetic for these layers, tests/golden/layers_small.npz) and (b) torch CPU autograd on the same
+modules.
+
+Tolerance: operands and stored activations are bf16 (8 significant bits), accumulation is fp32.
+Against an fp32 reference evaluated on the SAME bf16-rounded operands only the output rounding and
+summation order remain: |err| <= 2^-8 * |ref| + 2^-8 * rms(ref).  Gradients pass through one or two
+further bf16 roundings -> 3 * that bound.
+"""
+
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+EPS = 2.0 ** -8
+
+
+def _bf(x):
+    return x.to(torch.bfloat16).to(torch.float32)
+
+
+def _close(got, ref, k=1.0, what=""):
+    got, ref = got.detach().float().cpu(), ref.detach().float().cpu()
+    rms = ref.pow(2).mean().sqrt().item()
+    bound = k * EPS * (ref.abs() + rms) + 1e-6
+    bad = (got - ref).abs() > bound
+    assert not bad.any(), f"{what}: {int(bad.sum())}/{bad.numel()} outside tolerance, max err {(got - ref).abs().max().item():.4g}, rms {rms:.4g}"
+
+
+def _run_both(mods_cpu, x, gy=None):
+    """run the same module list on CPU (stock torch, bf16-rounded weights) and on the GPU plan"""
+    from yolo import engine
+    import copy
+    mods_gpu = copy.deepcopy(mods_cpu).cuda()
+    with torch.no_grad():
+        for m in mods_cpu:
+            if hasattr(m, "weight"):
+                m.weight.copy_(_bf(m.weight))
+    xc = _bf(x).clone().requires_grad_(True)
+    yc = mods_cpu(xc)
+    plan = engine.Plan.from_modules(list(mods_gpu), x.shape[1], False)
+    xg = x.clone().cuda().requires_grad_(True)
+    mods_gpu.eval()
+    yg = engine.run_plan(plan, xg, False)
+    if gy is None:
+        return yc, yg, None, None
+    yc.backward(gy)
+    yg.backward(gy.cuda())
+    gc = [xc.grad] + [p.grad for p in mods_cpu.parameters()]
+    gg = [xg.grad] + [p.grad for p in mods_gpu.parameters()]
+    return yc, yg, gc, gg
+
+
+def test_golden_conv_layers(golden):
+    g = golden("layers_small.npz")
+    for name in ("c3x3", "c3x3s2", "c1x1"):
+        ks, st, pd = (int(v) for v in g[f"{name}__cfg"])
+        w = torch.from_numpy(g[f"{name}__w"])
+        conv = nn.Conv2d(w.shape[1], w.shape[0], ks, st, pd)
+        with torch.no_grad():
+            conv.weight.copy_(w)
+            conv.bias.copy_(torch.from_numpy(g[f"{name}__b"]))
+        mods = nn.Sequential(conv, nn.LeakyReLU(0.1))
+        x = torch.from_numpy(g[f"{name}__x"])
+        gy = torch.from_numpy(g[f"{name}__gy"])
+        yc, yg, gc, gg = _run_both(mods, x, gy)
+        _close(yg, yc, 1.0, f"{name} y")
+        # and against the fp32 fixture itself (adds the operand rounding: sqrt(K) * 2^-8 relative)
+        assert (yg.cpu() - torch.from_numpy(g[f"{name}__y"])).abs().max() < 0.05
+        for a, b, what in zip(gg, gc, ("gx", "gw", "gb")):
+            _close(a, b, 3.0, f"{name} {what}")
+        assert (gg[1].cpu() - torch.from_numpy(g[f"{name}__gw"])).abs().max() < 0.03 * np.abs(g[f"{name}__gw"]).max() + 0.02
+
+
+def test_first_layer_7x7_s2_and_pool(golden):
+    g = golden("layers_small.npz")
+    w = torch.from_numpy(g["c7x7s2__w"])
+    conv = nn.Conv2d(3, 64, 7, 2, 3)
+    with torch.no_grad():
+        conv.weight.copy_(w)
+        conv.bias.copy_(torch.from_numpy(g["c7x7s2__b"]))
+    from yolo import engine
+    import copy
+    mods_c = nn.Sequential(conv, nn.LeakyReLU(0.1), nn.MaxPool2d(2, 2))
+    mods_g = copy.deepcopy(mods_c).cuda()
+    with torch.no_grad():
+        conv.weight.copy_(_bf(conv.weight))
+    x = torch.from_numpy(g["c7x7s2__x"])
+    yc = mods_c(_bf(x))
+    plan = engine.Plan.from_modules(list(mods_g), 3, True)
+    yg = engine.run_plan(plan, x.cuda(), False)
+    _close(yg, yc, 1.0, "7x7s2+pool y")
+    gy = torch.randn(yc.shape, generator=torch.Generator().manual_seed(3))
+    yc.backward(gy)
+    yg.backward(gy.cuda())
+    _close(mods_g[0].weight.grad, conv.weight.grad, 3.0, "7x7s2 gw")
+    _close(mods_g[0].bias.grad, conv.bias.grad, 3.0, "7x7s2 gb")
+
+
+def test_maxpool_exact(golden):
+    """bf16 inputs that are exactly representable -> forward pool is exact; backward routes to the first max."""
+    from yolo import engine
+    g = golden("layers_small.npz")
+    x = _bf(torch.from_numpy(g["pool__x"]))
+    conv = nn.Conv2d(32, 32, 1)
+    with torch.no_grad():
+        conv.weight.zero_()
+        conv.weight[:, :, 0, 0] = torch.eye(32)
+        conv.bias.zero_()
+    mods = nn.Sequential(conv, nn.LeakyReLU(0.1), nn.MaxPool2d(2, 2))
+    yc, yg, gc, gg = _run_both(mods, x, torch.from_numpy(g["pool__gy"]))
+    assert torch.equal(yg.cpu(), yc)
+    _close(gg[0], gc[0], 1.0, "pool gx")
+
+
+def test_conv_pool_conv_chain_and_tails():
+    """odd sizes: pixel-tile tails (M not a multiple of 128), Cout=192 (3 x 64 tiles), stride-2 in the middle."""
+    torch.manual_seed(0)
+    mods = nn.Sequential(
+        nn.Conv2d(64, 192, 3, 1, 1), nn.LeakyReLU(0.1), nn.MaxPool2d(2, 2),
+        nn.Conv2d(192, 128, 1), nn.LeakyReLU(0.1),
+        nn.Conv2d(128, 256, 3, 2, 1), nn.LeakyReLU(0.1),
+        nn.Conv2d(256, 64, 3, 1, 1), nn.LeakyReLU(0.1))
+    x = torch.randn(3, 64, 20, 28)
+    yc0 = mods(x)
+    gy = torch.randn(yc0.shape)
+    yc, yg, gc, gg = _run_both(mods, x, gy)
+    _close(yg, yc, 2.0, "chain y")
+    for i, (a, b) in enumerate(zip(gg, gc)):
+        _close(a, b, 6.0, f"chain grad {i}")
+
+
+def test_fc_head_split_k():
+    """Flatten -> Linear(K=6272) (split-K atomics) -> LeakyReLU -> Dropout(eval) -> Linear(1470 outputs: ragged tile)."""
+    torch.manual_seed(1)
+    mods = nn.Sequential(
+        nn.Conv2d(64, 128, 3, 1, 1), nn.LeakyReLU(0.1),
+        nn.Flatten(), nn.Linear(128 * 7 * 7, 512), nn.LeakyReLU(0.1), nn.Dropout(0.5), nn.Linear(512, 1470))
+    mods.eval()
+    x = torch.randn(5, 64, 7, 7)
+    gy = torch.randn(5, 1470)
+    yc, yg, gc, gg = _run_both(mods, x, gy)
+    _close(yg, yc, 2.0, "fc y")
+    for i, (a, b) in enumerate(zip(gg, gc)):
+        _close(a, b, 6.0, f"fc grad {i}")
+
+
+def test_dropout_training_mask_consistency():
+    """training mode: the mask drawn in forward is the one applied in backward (grad zero where output zero)."""
+    from yolo import engine
+    torch.manual_seed(2)
+    mods = nn.Sequential(nn.Flatten(), nn.Linear(64 * 4 * 4, 256), nn.LeakyReLU(0.1), nn.Dropout(0.5), nn.Linear(256, 24)).cuda()
+    conv = nn.Sequential(nn.Conv2d(64, 64, 1), nn.LeakyReLU(0.1)).cuda()
+    plan = engine.Plan.from_modules(list(conv) + list(mods), 64, False)
+    x = torch.randn(4, 64, 4, 4, device="cuda")
+    y = engine.run_plan(plan, x, True)
+    y.sum().backward()
+    gw2 = mods[4].weight.grad            # (24, 256): column k is zero iff unit k was dropped for every sample
+    dropped_cols = (gw2.abs().sum(0) == 0).sum().item()
+    assert 0 < dropped_cols < 256 * 0.3   # P(all 4 samples dropped) = 1/16
+    assert torch.isfinite(y).all()
+
+
+def test_layout_roundtrip():
+    from yolo._hip import lib, check, ptr, stream
+    x = torch.randn(2, 40, 9, 11, device="cuda")
+    from yolo.engine import Act
+    a = Act(2, 9, 11, 40, 1, x.device)
+    check(lib().yolo_nchw_f32_to_nhwc_bf16(ptr(x), 2, 40, 9, 11, a.p, 40, 1, 1, stream()))
+    back = torch.empty_like(x)
+    check(lib().yolo_nhwc_bf16_to_nchw_f32(a.p, 2, 40, 9, 11, 1, ptr(back), stream()))
+    assert torch.equal(back, _bf(x))
+    v = a.view()
+    assert v[:, 0].abs().sum() == 0 and v[:, -1].abs().sum() == 0 and v[:, :, 0].abs().sum() == 0 and v[:, :, -1].abs().sum() == 0

@@ -1,0 +1,72 @@
+"""GPU parity: fused HIP loss forward+backward (C ABI) vs reference fixtures and the oracle.
+Bar (north_star): <= 1e-4 on the fp32 loss; gradients to fp32 round-off."""
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from yolo import ops as _ops
+    return _ops
+
+
+def test_golden_loss_cases(ops, golden):
+    g = golden("loss_cases.npz")
+    for name in [str(n) for n in g["names"]]:
+        lc, ln = (float(v) for v in g[f"{name}__lambdas"])
+        out, dpred = ops.loss_fwd_bwd(torch.from_numpy(g[f"{name}__pred"]).cuda(), torch.from_numpy(g[f"{name}__tgt"]).cuda(), 7, 2, 20, lc, ln)
+        out = out.cpu().numpy()
+        ref5 = g[f"{name}__out5"]
+        assert out[5] == 0.0
+        assert np.max(np.abs(out[:5] - ref5)) <= 1e-4 * max(1.0, np.max(np.abs(ref5))), (name, out[:5], ref5)
+        np.testing.assert_allclose(out[:5], ref5, rtol=1e-5, atol=1e-6, err_msg=name)
+        np.testing.assert_allclose(dpred.cpu().numpy(), g[f"{name}__dpred"], rtol=2e-5, atol=2e-6, err_msg=name)
+
+
+def test_batch64_and_512_vs_oracle(ops):
+    import synth
+    for N, seed in ((64, 3), (512, 4)):
+        pred = synth.synth_normal((N, 7, 7, 30), 900 + seed, 0.5, seed) + 0.25
+        tgt = synth.synth_targets(N, seed)
+        out, dpred = ops.loss_fwd_bwd(torch.from_numpy(pred).cuda(), torch.from_numpy(tgt).cuda(), 7, 2, 20, 5.0, 0.5)
+        ref5, refg = O.loss_fwd_bwd(pred, tgt)
+        np.testing.assert_allclose(out.cpu().numpy()[:5], ref5, rtol=1e-5, atol=1e-6)
+        # same fp32 per-cell arithmetic on both sides -> gradients agree to the last bits
+        np.testing.assert_allclose(dpred.cpu().numpy(), refg, rtol=1e-6, atol=1e-8)
+
+
+def test_error_flag_for_bad_target_slot(ops):
+    t = np.zeros((2, 7, 7, 30), np.float32)
+    t[1, 1, 1, 14] = 1.0
+    out, _ = ops.loss_fwd_bwd(torch.zeros((2, 7, 7, 30)).cuda(), torch.from_numpy(t).cuda(), 7, 2, 20, 5.0, 0.5)
+    assert out.cpu().numpy()[5] == 1.0
+
+
+def test_loss_iou(ops, golden):
+    g = golden("loss_cases.npz")
+    out = ops.loss_iou(torch.from_numpy(g["iou__b1"]).cuda(), torch.from_numpy(g["iou__b2"]).cuda())
+    np.testing.assert_allclose(out.cpu().numpy(), g["iou__out"], rtol=1e-6, atol=1e-7)
+
+
+def test_other_shapes(ops):
+    """B=3, C=7, S=5: the 4::5 slice then covers channels 4,9,14,19."""
+    rng = np.random.Generator(np.random.PCG64([5, 98]))
+    S, B, C = 5, 3, 7
+    D = B * 5 + C
+    pred = rng.standard_normal(size=(6, S, S, D)).astype(np.float32) * 0.5 + 0.3
+    tgt = np.zeros((6, S, S, D), np.float32)
+    for n in range(6):
+        for _ in range(4):
+            i, j, slot = rng.integers(0, S), rng.integers(0, S), rng.integers(0, B)
+            tgt[n, i, j, slot * 5: slot * 5 + 5] = [*rng.uniform(0, 1, 2), *rng.uniform(0.1, 0.9, 2), 1.0]
+            tgt[n, i, j, B * 5 + rng.integers(0, C)] = 1.0
+    out, dpred = ops.loss_fwd_bwd(torch.from_numpy(pred).cuda(), torch.from_numpy(tgt).cuda(), S, B, C, 5.0, 0.5)
+    ref5, refg = O.loss_fwd_bwd(pred, tgt, S, B, C)
+    np.testing.assert_allclose(out.cpu().numpy()[:5], ref5, rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(dpred.cpu().numpy(), refg, rtol=1e-6, atol=1e-8)

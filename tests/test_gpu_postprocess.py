@@ -1,0 +1,124 @@
+"""GPU parity: HIP decode / IoU / NMS (through the C ABI) vs the oracle and the reference fixtures.
+Bar: bit-exact records (fp64), class ids and kept indices."""
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from yolo import ops as _ops
+    return _ops
+
+
+def _run(ops, pred_np, ct, nt, variant):
+    pred = torch.from_numpy(pred_np).cuda()
+    return ops.postprocess_host(pred, ct, nt, variant, 7, 2, 20)
+
+
+def test_golden_decode_nms_bit_exact(ops, golden):
+    g = golden("post_cases.npz")
+    for name in [str(n) for n in g["names"]]:
+        pred = g[f"{name}__pred"]
+        ct, nt = (float(v) for v in g[f"{name}__thr"])
+        res_m = _run(ops, pred, ct, nt, 1)
+        res_i = _run(ops, pred, ct, nt, 0)
+        for n in range(pred.shape[0]):
+            rec, keep = res_m[n]
+            assert rec.shape == g[f"{name}__m{n}_dec"].shape, (name, n)
+            assert np.array_equal(rec, g[f"{name}__m{n}_dec"]), (name, n)
+            assert np.array_equal(keep, g[f"{name}__m{n}_keep"]), (name, n, "metrics order")
+            if f"{name}__i{n}_keep" in g:
+                assert np.array_equal(res_i[n][1], g[f"{name}__i{n}_keep"]), (name, n, "inference order")
+
+
+def test_crafted_lists_bit_exact(ops, golden):
+    g = golden("post_cases.npz")
+    for name in [str(n) for n in g["crafted"]] + ["negw"]:
+        rec = g[f"craft_{name}__in"]
+        thr = float(g[f"craft_{name}__thr"][0])
+        n = len(rec)
+        rec_d = torch.zeros((1, 128, 6), dtype=torch.float64, device="cuda")
+        rec_d[0, :n] = torch.from_numpy(rec).cuda()
+        cnt = torch.tensor([n], dtype=torch.int32, device="cuda")
+        keep, kc = ops.nms(rec_d, cnt, thr, 1)
+        assert np.array_equal(keep[0, : int(kc[0])].cpu().numpy(), g[f"craft_{name}__mkeep"]), name
+        if f"craft_{name}__ikeep" in g:
+            keep, kc = ops.nms(rec_d, cnt, thr, 0)
+            assert np.array_equal(keep[0, : int(kc[0])].cpu().numpy(), g[f"craft_{name}__ikeep"]), name
+
+
+def test_config5_batch64_vs_oracle(ops):
+    """BASELINE config 5's post-processing input: (64,7,7,30) ~U(0,1), conf 0.3, nms 0.4."""
+    rng = np.random.Generator(np.random.PCG64([0, 99]))
+    pred = rng.uniform(0, 1, size=(64, 7, 7, 30)).astype(np.float32)
+    for variant in (0, 1):
+        res = _run(ops, pred, 0.3, 0.4, variant)
+        tot = kept = 0
+        for n in range(64):
+            rec = O.decode(pred[n], 0.3)
+            assert np.array_equal(res[n][0], rec), n
+            assert np.array_equal(res[n][1], O.nms(rec, 0.4, variant)), (n, variant)
+            tot += len(rec)
+            kept += len(res[n][1])
+        assert tot > 3000 and 0 < kept < tot
+
+
+def test_raw_outputs_and_ties_vs_oracle(ops):
+    """Un-normalised network-like outputs (negative w/h, conf > 1), heavy ties, empty images."""
+    rng = np.random.Generator(np.random.PCG64([1, 99]))
+    pred = (rng.standard_normal(size=(32, 7, 7, 30)) * 0.5 + 0.3).astype(np.float32)
+    pred[5] = 0.0                      # nothing survives
+    pred[6, ..., 4] = 0.5              # all-equal confidences
+    pred[6, ..., 9] = 0.5
+    pred[6, ..., 10:] = 0.5            # class tie -> argmax 0
+    pred[7] = np.round(pred[7] * 4) / 4  # quantised -> many equal confidences and IoUs
+    for variant in (0, 1):
+        for ct, nt in ((0.01, 0.4), (0.1, 0.3), (-1.0, 0.5)):
+            res = _run(ops, pred, ct, nt, variant)
+            for n in range(pred.shape[0]):
+                rec = O.decode(pred[n], ct)
+                assert np.array_equal(res[n][0], rec), (n, ct)
+                assert np.array_equal(res[n][1], O.nms(rec, nt, variant)), (n, variant, ct, nt)
+
+
+def test_ground_truth_decode(ops, golden):
+    g = golden("post_cases.npz")
+    tg = g["gt__tgt"]
+    rec, cnt = ops.decode_gt(torch.from_numpy(tg).cuda(), 7, 2, 20)
+    rec, cnt = rec.cpu().numpy(), cnt.cpu().numpy()
+    for n in range(tg.shape[0]):
+        assert np.array_equal(rec[n, : cnt[n]], g[f"gt__{n}"])
+
+
+def test_pairwise_iou_bit_exact(ops, golden):
+    g = golden("post_cases.npz")
+    pairs = g["ioupairs__in"]
+    a = torch.from_numpy(pairs[:, :4]).cuda()
+    b = torch.from_numpy(pairs[:, 4:]).cuda()
+    for variant, key in ((0, "ioupairs__inference"), (1, "ioupairs__metrics")):
+        m = ops.pairwise_iou(a, b, variant).cpu().numpy()
+        assert np.array_equal(np.diag(m), g[key])
+        # off-diagonal entries against the oracle
+        for i in (0, 3, 17):
+            for j in (1, 9, 40):
+                assert m[i, j] == O.iou(pairs[i, :4], pairs[j, 4:], variant)
+
+
+def test_other_grid_sizes(ops):
+    """S=14 / B=3 / C=5 -> 588 candidates per image: decode loops, NMS limit respected."""
+    rng = np.random.Generator(np.random.PCG64([2, 99]))
+    S, B, C = 11, 1, 5
+    pred = rng.uniform(0, 1, size=(3, S, S, B * 5 + C)).astype(np.float32)
+    rec, cnt = ops.decode(torch.from_numpy(pred).cuda(), 0.2, S, B, C)
+    rec, cnt = rec.cpu().numpy(), cnt.cpu().numpy()
+    for n in range(3):
+        assert np.array_equal(rec[n, : cnt[n]], O.decode(pred[n], 0.2, S, B, C))
+    keep, kc = ops.nms(torch.from_numpy(rec).cuda(), torch.from_numpy(cnt).cuda(), 0.4, 1)
+    for n in range(3):
+        assert np.array_equal(keep[n, : int(kc[n])].cpu().numpy(), O.nms(rec[n, : cnt[n]], 0.4, 1))

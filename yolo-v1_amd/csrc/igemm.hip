@@ -1,0 +1,352 @@
+// Implicit-GEMM convolution / Linear kernel for gfx950 (CDNA4): bf16 operands, fp32 MFMA accumulate.
+//
+//   out[px][co] = epi( sum_{tap, c} in[row(px) + tapoff(tap) + c] * w[co][tap][c] )
+//
+// im2col-free: the "B" operand rows are gathered straight from the zero-haloed NHWC activation by
+// per-lane source addresses of `global_load_lds` (LDS-DMA, 16 B per lane), so a 3x3/pad-1 conv needs
+// neither an unfolded buffer nor bounds checks.  The same kernel runs
+//   * Conv2d + LeakyReLU(0.1) forward (src/yolo/models.py:47-84, :313-322 of the reference),
+//   * the conv data-gradient (weights pre-packed transposed + flipped, epilogue multiplies by the
+//     previous LeakyReLU's derivative),
+//   * Linear forward / data-gradient of the FC head (models.py:239-245) as a 1x1 conv on a 1x1 image.
+//
+// Structure (per 256-thread workgroup = 4 wave64, one per SIMD):
+//   tile  TCO output channels x TPX output pixels, K step BK (one tap, BK channels)
+//   LDS   2 stages x (TCO + TPX) rows x BK bf16, 16-B slots XOR-swizzled inside each 256-B bank row
+//         (conflict-free ds_read_b128 for the 32x32x16 operand maps); the swizzle is applied on the
+//         per-lane SOURCE address because an LDS-DMA writes lane-linear
+//   MFMA  v_mfma_f32_32x32x16_bf16, A = weights (rows = co), B = activations (cols = px); each
+//         wave owns (TCO/2) x (TPX/2)
+//   epilogue  accumulators -> LDS fp32 [px][co] -> bias / LeakyReLU / dLeakyReLU -> 16-B coalesced
+//         bf16 stores along the channel axis (full 128/256-B lines per pixel)
+//   split-K over blockIdx.y with fp32 atomics (Linear layers: M = batch is tiny, K = 50176)
+//   block ids are remapped so that each XCD (private L2) works on a contiguous range of tiles.
+#include "common.h"
+
+namespace yolo {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+struct IgemmParams {
+    const bf16_t *in;
+    const bf16_t *w;
+    const float *bias;
+    const bf16_t *aux;
+    void *out;
+    long M;                 // N*Ho*Wo output pixels
+    int HoWo, Wo;
+    long in_img_stride;
+    int in_row_stride, in_px_stride, in_off, stride;
+    int KH, KW, tap_len, Cout;
+    long Ktot;              // KH*KW*tap_len
+    long out_img_stride;
+    int out_row_stride, out_px_stride, out_off;
+    long aux_img_stride;
+    int aux_row_stride, aux_px_stride, aux_off;
+    int epilogue;
+    float slope;
+    int out_fp32;
+    int nk;                 // K iterations in total
+    int nk_per_split;
+    int n_co_tiles, n_px_tiles;
+};
+
+#define GLDS16(gptr, lptr) \
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gptr), (__attribute__((address_space(3))) void *)(lptr), 16, 0, 0)
+
+// LDS byte offset of 16-B chunk `chunk` of row `r` of a [rows][BK] bf16 tile (see header comment)
+template <int BK>
+__device__ __forceinline__ int lds_off(int r, int chunk)
+{
+    constexpr int CPR = BK / 8;        // 16-B chunks per row (8 or 4)
+    constexpr int RPB = 16 / CPR;      // rows per 256-B bank row (2 or 4)
+    const int R = r / RPB;
+    const int s = (r % RPB) * CPR + chunk;
+    return R * 256 + ((s ^ (R & 15)) << 4);
+}
+
+template <int TCO, int TPX, int BK>
+struct IgemmCfg {
+    static constexpr int A_BYTES = TCO * BK * 2;
+    static constexpr int B_BYTES = TPX * BK * 2;
+    static constexpr int STAGE_BYTES = A_BYTES + B_BYTES;
+    static constexpr int EP = TCO + 4;                       // fp32 epilogue row pitch (floats)
+    static constexpr int EPI_BYTES = TPX * EP * 4;
+    static constexpr int TABLE_BYTES = TPX * 32;             // per pixel: in_base, out_base, aux_base (int64 each, padded to 4)
+    static constexpr int MAIN_BYTES = (2 * STAGE_BYTES > EPI_BYTES) ? 2 * STAGE_BYTES : EPI_BYTES;
+    static constexpr int LDS_BYTES = TABLE_BYTES + MAIN_BYTES;
+    static constexpr int A_INSTR = A_BYTES / 1024 / 4;       // glds wave-instructions per wave per stage
+    static constexpr int B_INSTR = B_BYTES / 1024 / 4;
+    static constexpr int MT = TCO / 64, NT = TPX / 64;       // 32x32 MFMA tiles per wave
+};
+
+template <int TCO, int TPX, int BK>
+__global__ void __launch_bounds__(256, 2) igemm_kernel(const IgemmParams p)
+{
+    using Cfg = IgemmCfg<TCO, TPX, BK>;
+    constexpr int MT = Cfg::MT, NT = Cfg::NT;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    long *tab = reinterpret_cast<long *>(smem);
+    char *stage_base = smem + Cfg::TABLE_BYTES;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wco = wave >> 1, wpx = wave & 1;
+
+    // ---- XCD-aware tile mapping: blocks b, b+8, b+16.. share an XCD; give each XCD a contiguous
+    // range of logical tiles (co-tile fastest) so its private L2 sees one activation tile being
+    // reused across the co-tiles and a narrow band of weight panels.  Bijective for any grid size.
+    const int nwg = p.n_co_tiles * p.n_px_tiles;
+    int bid = blockIdx.x;
+    {
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, k = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+    }
+    const int co_tile = bid % p.n_co_tiles, px_tile = bid / p.n_co_tiles;
+    const int co0 = co_tile * TCO;
+    const long px0 = (long)px_tile * TPX;
+
+    // ---- per-pixel address tables (input row base / output base), one pixel per thread
+    if (tid < TPX) {
+        long m = px0 + tid;
+        const bool valid = m < p.M;
+        if (!valid) m = p.M - 1;
+        const int n = (int)(m / p.HoWo);
+        const int rem = (int)(m - (long)n * p.HoWo);
+        const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+        tab[4 * tid] = (long)n * p.in_img_stride + (long)(oy * p.stride) * p.in_row_stride + (long)(ox * p.stride) * p.in_px_stride + p.in_off;
+        tab[4 * tid + 1] = valid ? ((long)n * p.out_img_stride + (long)oy * p.out_row_stride + (long)ox * p.out_px_stride + p.out_off) : -1;
+        tab[4 * tid + 2] = (long)n * p.aux_img_stride + (long)oy * p.aux_row_stride + (long)ox * p.aux_px_stride + p.aux_off;
+    }
+    __syncthreads();
+
+    // ---- LDS-DMA source pointers (fixed rows/chunks per lane; only the K offset moves)
+    const bf16_t *a_src[Cfg::A_INSTR];
+    const bf16_t *b_src[Cfg::B_INSTR];
+    int a_dst[Cfg::A_INSTR], b_dst[Cfg::B_INSTR];
+    {
+        constexpr int CPR = BK / 8, RPB = 16 / CPR;
+#pragma unroll
+        for (int i = 0; i < Cfg::A_INSTR; ++i) {
+            const int q = i * 4 + wave;             // wave-instruction index inside the A tile
+            const int pos = q * 64 + lane;          // 16-B slot written by this lane
+            const int R = pos >> 4, s = (pos & 15) ^ (R & 15);
+            const int r = R * RPB + s / CPR, chunk = s % CPR;
+            int co = co0 + r;
+            if (co >= p.Cout) co = p.Cout - 1;
+            a_src[i] = p.w + (long)co * p.Ktot + chunk * 8;
+            a_dst[i] = q * 1024;
+        }
+#pragma unroll
+        for (int i = 0; i < Cfg::B_INSTR; ++i) {
+            const int q = i * 4 + wave;
+            const int pos = q * 64 + lane;
+            const int R = pos >> 4, s = (pos & 15) ^ (R & 15);
+            const int r = R * RPB + s / CPR, chunk = s % CPR;
+            b_src[i] = p.in + tab[4 * r] + chunk * 8;
+            b_dst[i] = Cfg::A_BYTES + q * 1024;
+        }
+    }
+
+    // ---- K range of this split
+    const int kbeg = blockIdx.y * p.nk_per_split;
+    const int kend = min(p.nk, kbeg + p.nk_per_split);
+    const int cpt = p.tap_len / BK;  // K iterations per tap
+    int tap = kbeg / cpt;
+    int c0 = (kbeg - tap * cpt) * BK;
+    int ky = tap / p.KW, kx = tap - ky * p.KW;
+
+    auto stage = [&](int buf, int kiter) {
+        char *sb = stage_base + buf * Cfg::STAGE_BYTES;
+        const long a_off = (long)kiter * BK;
+        const long b_off = (long)ky * p.in_row_stride + (long)kx * p.in_px_stride + c0;
+#pragma unroll
+        for (int i = 0; i < Cfg::A_INSTR; ++i) GLDS16(a_src[i] + a_off, sb + a_dst[i]);
+#pragma unroll
+        for (int i = 0; i < Cfg::B_INSTR; ++i) GLDS16(b_src[i] + b_off, sb + b_dst[i]);
+        c0 += BK;
+        if (c0 == p.tap_len) {
+            c0 = 0;
+            if (++kx == p.KW) { kx = 0; ++ky; }
+        }
+    };
+
+    // ---- fragment read offsets: lane l reads row (l&31), k-half (l>>5) of each 16-deep k-step
+    int a_rd[MT], b_rd[NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) a_rd[i] = lds_off<BK>(wco * (TCO / 2) + i * 32 + (lane & 31), lane >> 5);
+#pragma unroll
+    for (int i = 0; i < NT; ++i) b_rd[i] = Cfg::A_BYTES + lds_off<BK>(wpx * (TPX / 2) + i * 32 + (lane & 31), lane >> 5);
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    if (kbeg < kend) stage(0, kbeg);
+    for (int it = kbeg; it < kend; ++it) {
+        const int buf = (it - kbeg) & 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();  // tile `it` has landed for every wave; buffer buf^1 is free again
+        if (it + 1 < kend) stage(buf ^ 1, it + 1);
+        const char *sb = stage_base + buf * Cfg::STAGE_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < BK / 16; ++ks) {
+            bf16x8 af[MT], bfr[NT];
+            // chunk index = 2*ks + (lane>>5); 2*ks only touches bits the row part left clear -> XOR
+#pragma unroll
+            for (int i = 0; i < MT; ++i) af[i] = *reinterpret_cast<const bf16x8 *>(sb + (a_rd[i] ^ (ks << 5)));
+#pragma unroll
+            for (int j = 0; j < NT; ++j) bfr[j] = *reinterpret_cast<const bf16x8 *>(sb + (b_rd[j] ^ (ks << 5)));
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+        }
+    }
+    __syncthreads();  // all MFMA operand reads done before the stage area is reused for the epilogue
+
+    // ---- epilogue 1: accumulators -> LDS fp32 [px][co]
+    // 32x32 C/D map: col (= pixel) = lane&31, row (= co) = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+    float *ep = reinterpret_cast<float *>(stage_base);
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int px = wpx * (TPX / 2) + j * 32 + (lane & 31);
+            const int cob = wco * (TCO / 2) + i * 32 + 4 * (lane >> 5);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4 v = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+                *reinterpret_cast<f32x4 *>(ep + px * Cfg::EP + cob + 8 * g) = v;
+            }
+        }
+    __syncthreads();
+
+    // ---- epilogue 2: coalesced along channels, 8 channels per thread per step
+    constexpr int CCH = TCO / 8;            // 8-channel chunks per pixel
+    constexpr int PX_PER_STEP = 256 / CCH;  // pixels covered by the workgroup per step
+    const int cc = tid % CCH;
+    const int co = co0 + cc * 8;
+    float bias8[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) bias8[k] = (p.epilogue == YOLO_EPI_BIAS || p.epilogue == YOLO_EPI_BIAS_LRELU) && (co + k < p.Cout) ? p.bias[co + k] : 0.0f;
+    const bool split = gridDim.y > 1;
+#pragma unroll 2
+    for (int px = tid / CCH; px < TPX; px += PX_PER_STEP) {
+        const long ob = tab[4 * px + 1];
+        if (ob < 0 || co >= p.Cout) continue;
+        float v[8];
+        const f32x4 lo = *reinterpret_cast<const f32x4 *>(ep + px * Cfg::EP + cc * 8);
+        const f32x4 hi = *reinterpret_cast<const f32x4 *>(ep + px * Cfg::EP + cc * 8 + 4);
+        v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3];
+        v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
+        if (p.epilogue == YOLO_EPI_BIAS || p.epilogue == YOLO_EPI_BIAS_LRELU) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] += bias8[k];
+        }
+        if (p.epilogue == YOLO_EPI_BIAS_LRELU) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = v[k] > 0.0f ? v[k] : v[k] * p.slope;
+        } else if (p.epilogue == YOLO_EPI_MUL_DLRELU) {
+            const uint4 y = *reinterpret_cast<const uint4 *>(p.aux + tab[4 * px + 2] + co);
+            const unsigned yy[4] = {y.x, y.y, y.z, y.w};
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const float a = __uint_as_float((k & 1) ? (yy[k >> 1] & 0xffff0000u) : (yy[k >> 1] << 16));
+                v[k] = a > 0.0f ? v[k] : v[k] * p.slope;
+            }
+        }
+        if (p.out_fp32) {
+            float *o = reinterpret_cast<float *>(p.out) + ob + co;
+            if (split) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+                    if (co + k < p.Cout) atomicAdd(o + k, v[k]);
+            } else if (co + 8 <= p.Cout && ((ob + co) & 3) == 0) {
+                *reinterpret_cast<f32x4 *>(o) = f32x4{v[0], v[1], v[2], v[3]};
+                *reinterpret_cast<f32x4 *>(o + 4) = f32x4{v[4], v[5], v[6], v[7]};
+            } else {
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+                    if (co + k < p.Cout) o[k] = v[k];
+            }
+        } else {
+            bf16_t *o = reinterpret_cast<bf16_t *>(p.out) + ob + co;
+            uint4 pk;
+            pk.x = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
+            pk.y = (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
+            pk.z = (unsigned)f32_to_bf16(v[4]) | ((unsigned)f32_to_bf16(v[5]) << 16);
+            pk.w = (unsigned)f32_to_bf16(v[6]) | ((unsigned)f32_to_bf16(v[7]) << 16);
+            *reinterpret_cast<uint4 *>(o) = pk;  // Cout % 8 == 0 is required for bf16 outputs
+        }
+    }
+}
+
+template <int TCO, int TPX, int BK>
+static int launch(const IgemmParams &p, int splits, hipStream_t s)
+{
+    using Cfg = IgemmCfg<TCO, TPX, BK>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&igemm_kernel<TCO, TPX, BK>), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
+        if (e != hipSuccess) return fail((int)e, "yolo_igemm: hipFuncSetAttribute(%d B LDS): %s", Cfg::LDS_BYTES, hipGetErrorString(e));
+        attr_done = true;
+    }
+    IgemmParams q = p;
+    q.n_co_tiles = (p.Cout + TCO - 1) / TCO;
+    q.n_px_tiles = (int)((p.M + TPX - 1) / TPX);
+    q.nk = (int)(p.Ktot / BK);
+    q.nk_per_split = (q.nk + splits - 1) / splits;
+    const int real_splits = (q.nk + q.nk_per_split - 1) / q.nk_per_split;
+    hipLaunchKernelGGL((igemm_kernel<TCO, TPX, BK>), dim3(q.n_co_tiles * q.n_px_tiles, real_splits), dim3(256), Cfg::LDS_BYTES, s, q);
+    return check_launch("yolo_igemm");
+}
+
+}  // namespace yolo
+
+using namespace yolo;
+
+YOLO_API int yolo_igemm(const yolo_igemm_desc *d, const void *in, const void *w, const float *bias, const void *aux, void *out, yolo_stream_t stream)
+{
+    if (!d || !in || !w || !out) return fail(YOLO_E_ARG, "yolo_igemm: null pointer");
+    if (d->N <= 0 || d->Ho <= 0 || d->Wo <= 0 || d->KH <= 0 || d->KW <= 0 || d->tap_len <= 0 || d->Cout <= 0 || d->stride <= 0)
+        return fail(YOLO_E_ARG, "yolo_igemm: bad descriptor");
+    if ((d->epilogue == YOLO_EPI_BIAS || d->epilogue == YOLO_EPI_BIAS_LRELU) && !bias) return fail(YOLO_E_ARG, "yolo_igemm: epilogue needs bias");
+    if (d->epilogue == YOLO_EPI_MUL_DLRELU && !aux) return fail(YOLO_E_ARG, "yolo_igemm: epilogue needs aux");
+    if (d->epilogue < 0 || d->epilogue > YOLO_EPI_MUL_DLRELU) return fail(YOLO_E_ARG, "yolo_igemm: epilogue %d", d->epilogue);
+    const int splits = d->split_k > 1 ? d->split_k : 1;
+    if (splits > 1 && (!d->out_fp32 || d->epilogue != YOLO_EPI_NONE)) return fail(YOLO_E_ARG, "yolo_igemm: split_k needs fp32 output and EPI_NONE");
+    if (!d->out_fp32 && ((d->Cout & 7) || (d->out_off & 7) || (d->out_px_stride & 7) || (d->out_row_stride & 7) || (d->out_img_stride & 7)))
+        return fail(YOLO_E_UNSUPPORTED, "yolo_igemm: bf16 output needs Cout and output strides in multiples of 8");
+    if ((d->tap_len & 31) || (d->in_off & 7) || (d->in_px_stride & 3) || (d->in_row_stride & 7) || (d->in_img_stride & 7))
+        return fail(YOLO_E_UNSUPPORTED, "yolo_igemm: tap_len=%d must be a multiple of 32 and input strides 16-B aligned", d->tap_len);
+
+    IgemmParams p{};
+    p.in = (const bf16_t *)in; p.w = (const bf16_t *)w; p.bias = bias; p.aux = (const bf16_t *)aux; p.out = out;
+    p.M = (long)d->N * d->Ho * d->Wo; p.HoWo = d->Ho * d->Wo; p.Wo = d->Wo;
+    p.in_img_stride = d->in_img_stride; p.in_row_stride = d->in_row_stride; p.in_px_stride = d->in_px_stride; p.in_off = d->in_off; p.stride = d->stride;
+    p.KH = d->KH; p.KW = d->KW; p.tap_len = d->tap_len; p.Cout = d->Cout;
+    p.Ktot = (long)d->KH * d->KW * d->tap_len;
+    p.out_img_stride = d->out_img_stride; p.out_row_stride = d->out_row_stride; p.out_px_stride = d->out_px_stride; p.out_off = d->out_off;
+    p.aux_img_stride = d->aux_img_stride; p.aux_row_stride = d->aux_row_stride; p.aux_px_stride = d->aux_px_stride; p.aux_off = d->aux_off;
+    p.epilogue = d->epilogue; p.slope = d->slope; p.out_fp32 = d->out_fp32;
+    hipStream_t s = STRM(stream);
+
+    const bool bk64 = (d->tap_len % 64) == 0;
+    const bool small_px = p.M <= 64;
+    const bool small_co = d->Cout <= 64 || (d->Cout % 128 != 0 && d->Cout % 64 == 0 && d->Cout < 512);
+    if (!bk64) {
+        if (small_co) return launch<64, 128, 32>(p, splits, s);
+        return launch<128, 128, 32>(p, splits, s);
+    }
+    if (small_px) return small_co ? launch<64, 64, 64>(p, splits, s) : launch<128, 64, 64>(p, splits, s);
+    if (small_co) return launch<64, 128, 64>(p, splits, s);
+    return launch<128, 128, 64>(p, splits, s);
+}

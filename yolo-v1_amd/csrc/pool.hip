@@ -1,0 +1,123 @@
+// MaxPool2d(2,2) forward and backward on zero-haloed NHWC bf16 (HBM-bound: 16 B per lane).
+// Replaces aten max_pool2d_with_indices{,_backward} for src/yolo/models.py:51,55,65,72; the
+// backward recomputes the arg-max from the stored (post-LeakyReLU) activation instead of keeping
+// an index tensor, and applies the LeakyReLU derivative of the layer in front of the pool in the
+// same pass (sign(lrelu(z)) == sign(z)).
+#include "common.h"
+
+namespace yolo {
+
+__device__ __forceinline__ void unpack8(const uint4 &v, float f[8])
+{
+    f[0] = __uint_as_float(v.x << 16); f[1] = __uint_as_float(v.x & 0xffff0000u);
+    f[2] = __uint_as_float(v.y << 16); f[3] = __uint_as_float(v.y & 0xffff0000u);
+    f[4] = __uint_as_float(v.z << 16); f[5] = __uint_as_float(v.z & 0xffff0000u);
+    f[6] = __uint_as_float(v.w << 16); f[7] = __uint_as_float(v.w & 0xffff0000u);
+}
+__device__ __forceinline__ uint4 pack8(const float f[8])
+{
+    uint4 o;
+    o.x = (unsigned)f32_to_bf16(f[0]) | ((unsigned)f32_to_bf16(f[1]) << 16);
+    o.y = (unsigned)f32_to_bf16(f[2]) | ((unsigned)f32_to_bf16(f[3]) << 16);
+    o.z = (unsigned)f32_to_bf16(f[4]) | ((unsigned)f32_to_bf16(f[5]) << 16);
+    o.w = (unsigned)f32_to_bf16(f[6]) | ((unsigned)f32_to_bf16(f[7]) << 16);
+    return o;
+}
+
+// one thread = one pooled pixel x 8 channels
+__global__ void __launch_bounds__(256) maxpool2_fwd_kernel(const bf16_t *__restrict__ x, int N, int H, int W, int C, int hi, int ho,
+                                                           bf16_t *__restrict__ y)
+{
+    const int C8 = C >> 3, Ho = H >> 1, Wo = W >> 1;
+    const long total = (long)N * Ho * Wo * C8;
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int c8 = (int)(idx % C8);
+    const int ox = (int)((idx / C8) % Wo);
+    const int oy = (int)((idx / ((long)C8 * Wo)) % Ho);
+    const int n = (int)(idx / ((long)C8 * Wo * Ho));
+    const int Wp = W + 2 * hi, Hp = H + 2 * hi;
+    const bf16_t *p = x + (((long)n * Hp + 2 * oy + hi) * Wp + 2 * ox + hi) * C + c8 * 8;
+    float a[8], b[8], c[8], d[8], m[8];
+    unpack8(*reinterpret_cast<const uint4 *>(p), a);
+    unpack8(*reinterpret_cast<const uint4 *>(p + C), b);
+    unpack8(*reinterpret_cast<const uint4 *>(p + (long)Wp * C), c);
+    unpack8(*reinterpret_cast<const uint4 *>(p + (long)Wp * C + C), d);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) m[k] = fmaxf(fmaxf(a[k], b[k]), fmaxf(c[k], d[k]));
+    const int Wop = Wo + 2 * ho, Hop = Ho + 2 * ho;
+    *reinterpret_cast<uint4 *>(y + (((long)n * Hop + oy + ho) * Wop + ox + ho) * C + c8 * 8) = pack8(m);
+}
+
+// one thread = one pooled pixel x 8 channels; writes the four un-pooled gradient pixels
+__global__ void __launch_bounds__(256) maxpool2_bwd_kernel(const bf16_t *__restrict__ yfull, const bf16_t *__restrict__ dpool, int N, int H,
+                                                           int W, int C, int hi, int ho, float slope, bf16_t *__restrict__ dz)
+{
+    const int C8 = C >> 3, Ho = H >> 1, Wo = W >> 1;
+    const long total = (long)N * Ho * Wo * C8;
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int c8 = (int)(idx % C8);
+    const int ox = (int)((idx / C8) % Wo);
+    const int oy = (int)((idx / ((long)C8 * Wo)) % Ho);
+    const int n = (int)(idx / ((long)C8 * Wo * Ho));
+    const int Wp = W + 2 * hi, Hp = H + 2 * hi;
+    const int Wop = Wo + 2 * ho, Hop = Ho + 2 * ho;
+    const long off = (((long)n * Hp + 2 * oy + hi) * Wp + 2 * ox + hi) * C + c8 * 8;
+    const bf16_t *p = yfull + off;
+    float v[4][8], g[8], o[4][8];
+    unpack8(*reinterpret_cast<const uint4 *>(p), v[0]);
+    unpack8(*reinterpret_cast<const uint4 *>(p + C), v[1]);
+    unpack8(*reinterpret_cast<const uint4 *>(p + (long)Wp * C), v[2]);
+    unpack8(*reinterpret_cast<const uint4 *>(p + (long)Wp * C + C), v[3]);
+    unpack8(*reinterpret_cast<const uint4 *>(dpool + (((long)n * Hop + oy + ho) * Wop + ox + ho) * C + c8 * 8), g);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        int am = 0;
+        float m = v[0][k];
+        if (v[1][k] > m) { m = v[1][k]; am = 1; }  // first maximum in (0,0),(0,1),(1,0),(1,1) order
+        if (v[2][k] > m) { m = v[2][k]; am = 2; }
+        if (v[3][k] > m) { m = v[3][k]; am = 3; }
+        const float gv = g[k] * (m > 0.0f ? 1.0f : slope);
+        o[0][k] = am == 0 ? gv : 0.0f;
+        o[1][k] = am == 1 ? gv : 0.0f;
+        o[2][k] = am == 2 ? gv : 0.0f;
+        o[3][k] = am == 3 ? gv : 0.0f;
+    }
+    bf16_t *q = dz + off;
+    *reinterpret_cast<uint4 *>(q) = pack8(o[0]);
+    *reinterpret_cast<uint4 *>(q + C) = pack8(o[1]);
+    *reinterpret_cast<uint4 *>(q + (long)Wp * C) = pack8(o[2]);
+    *reinterpret_cast<uint4 *>(q + (long)Wp * C + C) = pack8(o[3]);
+}
+
+}  // namespace yolo
+
+using namespace yolo;
+
+static int pool_args(const yolo_pool_desc *d, const char *who)
+{
+    if (!d || d->N <= 0 || d->H <= 0 || d->W <= 0 || d->C <= 0 || d->in_halo < 0 || d->out_halo < 0) return fail(YOLO_E_ARG, "%s: bad descriptor", who);
+    if ((d->C & 7) || (d->H & 1) || (d->W & 1)) return fail(YOLO_E_UNSUPPORTED, "%s: C=%d must be a multiple of 8 and H,W=%d,%d even", who, d->C, d->H, d->W);
+    return 0;
+}
+
+YOLO_API int yolo_maxpool2_fwd(const yolo_pool_desc *d, const void *x, void *y, yolo_stream_t stream)
+{
+    if (int rc = pool_args(d, "yolo_maxpool2_fwd")) return rc;
+    if (!x || !y) return fail(YOLO_E_ARG, "yolo_maxpool2_fwd: null pointer");
+    const long total = (long)d->N * (d->H / 2) * (d->W / 2) * (d->C / 8);
+    hipLaunchKernelGGL(maxpool2_fwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, STRM(stream), (const bf16_t *)x, d->N, d->H, d->W, d->C,
+                       d->in_halo, d->out_halo, (bf16_t *)y);
+    return check_launch("yolo_maxpool2_fwd");
+}
+
+YOLO_API int yolo_maxpool2_bwd_lrelu(const yolo_pool_desc *d, const void *yfull, const void *dpool, float slope, void *dz, yolo_stream_t stream)
+{
+    if (int rc = pool_args(d, "yolo_maxpool2_bwd_lrelu")) return rc;
+    if (!yfull || !dpool || !dz) return fail(YOLO_E_ARG, "yolo_maxpool2_bwd_lrelu: null pointer");
+    const long total = (long)d->N * (d->H / 2) * (d->W / 2) * (d->C / 8);
+    hipLaunchKernelGGL(maxpool2_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, STRM(stream), (const bf16_t *)yfull, (const bf16_t *)dpool,
+                       d->N, d->H, d->W, d->C, d->in_halo, d->out_halo, slope, (bf16_t *)dz);
+    return check_launch("yolo_maxpool2_bwd_lrelu");
+}

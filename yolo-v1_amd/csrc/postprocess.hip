@@ -1,0 +1,294 @@
+// S x S x B box decode, pairwise IoU and per-image NMS for gfx950 -- wavefront primitives
+// (64-lane ballot / popcount prefix), no MFMA.  Everything is fp64 arithmetic on fp32 inputs in
+// the reference's Python operation order; this file MUST be compiled with -ffp-contract=off so
+// that no multiply-add pair is fused (bit-exact confidences / IoUs => bit-exact kept indices).
+//
+// Reference behaviour restated (mattiaskvist/yolo-v1):
+//   decode   src/yolo/inference.py:170-210, src/yolo/metrics.py:185-218, :232-256
+//   IoU      src/yolo/inference.py:229-249 + src/yolo/schemas.py:18-55 ; src/yolo/metrics.py:313-341
+//   NMS      src/yolo/inference.py:298-317 ; src/yolo/metrics.py:270-296
+#include "common.h"
+
+namespace yolo {
+
+#pragma clang fp contract(off)
+
+// ------------------------------------------------------------------------------------------------
+// decode: one workgroup (128 threads = 2 waves) per image; candidate t = (cell, box) in scan order.
+// Compaction keeps scan order: rank inside a wave = popcount of the ballot below the lane, waves
+// are chained through LDS.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(128) decode_kernel(const float *__restrict__ pred, int S, int B, int C, double thr,
+                                                     double *__restrict__ rec, int *__restrict__ counts)
+{
+    const int D = B * 5 + C;
+    const int ncand = S * S * B;
+    const int img = blockIdx.x;
+    const float *p = pred + (size_t)img * S * S * D;
+    double *out = rec + (size_t)img * ncand * 6;
+    __shared__ int wave_cnt[2];
+    __shared__ int base_s;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) base_s = 0;
+    __syncthreads();
+    for (int t0 = 0; t0 < ncand; t0 += 128) {
+        const int t = t0 + threadIdx.x;
+        bool keep = false;
+        double r0 = 0, r1 = 0, r2 = 0, r3 = 0, r4 = 0, r5 = 0;
+        if (t < ncand) {
+            const int cell = t / B, b = t - cell * B;
+            const int i = cell / S, j = cell - i * S;
+            const float *c = p + (size_t)cell * D;
+            // torch.argmax: first maximum
+            int cls = 0;
+            float best = c[B * 5];
+            for (int k = 1; k < C; ++k) {
+                float v = c[B * 5 + k];
+                if (v > best) { best = v; cls = k; }
+            }
+            const float *bx = c + b * 5;
+            const double prob = (double)best;
+            r2 = ((double)j + (double)bx[0]) / (double)S;
+            r3 = ((double)i + (double)bx[1]) / (double)S;
+            r4 = (double)bx[2];
+            r5 = (double)bx[3];
+            r1 = (double)bx[4] * prob;
+            r0 = (double)cls;
+            keep = r1 > thr;
+        }
+        const unsigned long long m = __ballot(keep);
+        const int below = __popcll(m & ((1ull << lane) - 1ull));
+        if (lane == 0) wave_cnt[wave] = __popcll(m);
+        __syncthreads();
+        const int base = base_s + (wave == 1 ? wave_cnt[0] : 0);
+        if (keep) {
+            double *r = out + (size_t)(base + below) * 6;
+            r[0] = r0; r[1] = r1; r[2] = r2; r[3] = r3; r[4] = r4; r[5] = r5;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) base_s += wave_cnt[0] + wave_cnt[1];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) counts[img] = base_s;
+}
+
+__global__ void __launch_bounds__(128) decode_gt_kernel(const float *__restrict__ tgt, int S, int B, int C,
+                                                        double *__restrict__ rec, int *__restrict__ counts)
+{
+    const int D = B * 5 + C;
+    const int ncell = S * S;
+    const int img = blockIdx.x;
+    const float *p = tgt + (size_t)img * ncell * D;
+    double *out = rec + (size_t)img * ncell * 5;
+    __shared__ int wave_cnt[2];
+    __shared__ int base_s;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) base_s = 0;
+    __syncthreads();
+    for (int t0 = 0; t0 < ncell; t0 += 128) {
+        const int cell = t0 + threadIdx.x;
+        bool keep = false;
+        double r0 = 0, r1 = 0, r2 = 0, r3 = 0, r4 = 0;
+        if (cell < ncell) {
+            const int i = cell / S, j = cell - i * S;
+            const float *c = p + (size_t)cell * D;
+            keep = c[4] > 0.0f;  // slot 0 only (metrics.py:239)
+            int cls = 0;
+            float best = c[B * 5];
+            for (int k = 1; k < C; ++k) {
+                float v = c[B * 5 + k];
+                if (v > best) { best = v; cls = k; }
+            }
+            r0 = (double)cls;
+            r1 = ((double)j + (double)c[0]) / (double)S;
+            r2 = ((double)i + (double)c[1]) / (double)S;
+            r3 = (double)c[2];
+            r4 = (double)c[3];
+        }
+        const unsigned long long m = __ballot(keep);
+        const int below = __popcll(m & ((1ull << lane) - 1ull));
+        if (lane == 0) wave_cnt[wave] = __popcll(m);
+        __syncthreads();
+        const int base = base_s + (wave == 1 ? wave_cnt[0] : 0);
+        if (keep) {
+            double *r = out + (size_t)(base + below) * 5;
+            r[0] = r0; r[1] = r1; r[2] = r2; r[3] = r3; r[4] = r4;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) base_s += wave_cnt[0] + wave_cnt[1];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) counts[img] = base_s;
+}
+
+// ------------------------------------------------------------------------------------------------
+// scalar IoU, both reference formulas.  Python's max(a, b) returns a unless b > a; max(0, v) is 0
+// unless v > 0.
+// ------------------------------------------------------------------------------------------------
+template <int VARIANT>
+__device__ __forceinline__ double iou_f64(double ax, double ay, double aw, double ah, double bx, double by, double bw, double bh)
+{
+    const double ax1 = ax - aw / 2, ay1 = ay - ah / 2, ax2 = ax + aw / 2, ay2 = ay + ah / 2;
+    const double bx1 = bx - bw / 2, by1 = by - bh / 2, bx2 = bx + bw / 2, by2 = by + bh / 2;
+    const double ix1 = bx1 > ax1 ? bx1 : ax1;
+    const double iy1 = by1 > ay1 ? by1 : ay1;
+    const double ix2 = bx2 < ax2 ? bx2 : ax2;
+    const double iy2 = by2 < ay2 ? by2 : ay2;
+    const double dw = ix2 - ix1, dh = iy2 - iy1;
+    const double inter = (dw > 0 ? dw : 0.0) * (dh > 0 ? dh : 0.0);
+    const double a1 = aw * ah, a2 = bw * bh;
+    if (VARIANT == YOLO_NMS_INFERENCE) return inter / (a1 + a2 - inter + 1e-6);
+    const double uni = a1 + a2 - inter;
+    if (uni == 0) return 0.0;
+    return inter / uni;
+}
+
+template <int VARIANT>
+__global__ void pairwise_iou_kernel(const double *__restrict__ a, int na, const double *__restrict__ b, int nb, double *__restrict__ out)
+{
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long)na * nb) return;
+    const int i = (int)(idx / nb), j = (int)(idx - (long)i * nb);
+    const double *p = a + 4 * (size_t)i, *q = b + 4 * (size_t)j;
+    out[idx] = iou_f64<VARIANT>(p[0], p[1], p[2], p[3], q[0], q[1], q[2], q[3]);
+}
+
+// ------------------------------------------------------------------------------------------------
+// NMS: ONE wavefront per image, two boxes per lane (n <= 128).
+//   1. stable descending rank by confidence (ties keep scan order, like sorted(reverse=True))
+//   2. greedy sweep in rank order; the suppression set of a kept box is produced by two 64-lane
+//      ballots and OR-ed into wave-uniform "removed" masks -> no barriers, no atomics
+//   3. variant 1 re-orders the survivors by (first appearance of their class, rank)
+// ------------------------------------------------------------------------------------------------
+template <int VARIANT>
+__global__ void __launch_bounds__(64) nms_kernel(const double *__restrict__ rec, const int *__restrict__ counts, int max_per_img,
+                                                 double thr, int *__restrict__ keep, int *__restrict__ keep_counts)
+{
+    const int img = blockIdx.x;
+    const int lane = threadIdx.x;
+    int n = counts[img];
+    if (n > max_per_img) n = max_per_img;
+    const double *r = rec + (size_t)img * max_per_img * 6;
+    int *kout = keep + (size_t)img * max_per_img;
+
+    __shared__ double s_conf[128];
+    __shared__ double s_box[128][4];  // in rank order
+    __shared__ double s_cls[128];     // in rank order
+    __shared__ int s_orig[128];       // rank -> original index
+    __shared__ int s_kept[128];       // kept ranks, ascending
+
+    for (int k = lane; k < n; k += 64) s_conf[k] = r[(size_t)k * 6 + 1];
+    __syncthreads();
+    for (int k = lane; k < n; k += 64) {
+        const double c = s_conf[k];
+        int rank = 0;
+        for (int j = 0; j < n; ++j) {
+            const double cj = s_conf[j];
+            rank += (cj > c) || (cj == c && j < k);
+        }
+        s_orig[rank] = k;
+        s_cls[rank] = r[(size_t)k * 6 + 0];
+        s_box[rank][0] = r[(size_t)k * 6 + 2];
+        s_box[rank][1] = r[(size_t)k * 6 + 3];
+        s_box[rank][2] = r[(size_t)k * 6 + 4];
+        s_box[rank][3] = r[(size_t)k * 6 + 5];
+    }
+    __syncthreads();
+
+    // this lane's two boxes (ranks lane and lane+64)
+    const int b0 = lane, b1 = lane + 64;
+    double c0 = -1, x0 = 0, y0 = 0, w0 = 0, h0 = 0, c1 = -1, x1 = 0, y1 = 0, w1 = 0, h1 = 0;
+    if (b0 < n) { c0 = s_cls[b0]; x0 = s_box[b0][0]; y0 = s_box[b0][1]; w0 = s_box[b0][2]; h0 = s_box[b0][3]; }
+    if (b1 < n) { c1 = s_cls[b1]; x1 = s_box[b1][0]; y1 = s_box[b1][1]; w1 = s_box[b1][2]; h1 = s_box[b1][3]; }
+
+    unsigned long long removed0 = 0, removed1 = 0;  // wave-uniform
+    int nk = 0;
+    for (int a = 0; a < n; ++a) {
+        const bool dead = a < 64 ? ((removed0 >> a) & 1ull) : ((removed1 >> (a - 64)) & 1ull);
+        if (dead) continue;  // uniform branch
+        if (lane == 0) s_kept[nk] = a;
+        ++nk;
+        const double ca = s_cls[a], xa = s_box[a][0], ya = s_box[a][1], wa = s_box[a][2], ha = s_box[a][3];
+        bool p0 = false, p1 = false;
+        if (b0 > a && b0 < n && c0 == ca) p0 = !(iou_f64<VARIANT>(xa, ya, wa, ha, x0, y0, w0, h0) < thr);
+        if (b1 > a && b1 < n && c1 == ca) p1 = !(iou_f64<VARIANT>(xa, ya, wa, ha, x1, y1, w1, h1) < thr);
+        removed0 |= __ballot(p0);
+        removed1 |= __ballot(p1);
+    }
+    __syncthreads();
+
+    if (VARIANT == YOLO_NMS_INFERENCE) {
+        for (int k = lane; k < nk; k += 64) kout[k] = s_orig[s_kept[k]];
+    } else {
+        // class buckets in first-appearance order of the sorted list (dict insertion order)
+        for (int k = lane; k < nk; k += 64) {
+            const int a = s_kept[k];
+            const double ca = s_cls[a];
+            int first = a;
+            for (int j = 0; j < a; ++j)
+                if (s_cls[j] == ca) { first = j; break; }
+            // position = number of survivors with a smaller (first, rank) key
+            int pos = 0;
+            for (int q = 0; q < nk; ++q) {
+                const int aq = s_kept[q];
+                const double cq = s_cls[aq];
+                int fq = aq;
+                for (int j = 0; j < aq; ++j)
+                    if (s_cls[j] == cq) { fq = j; break; }
+                pos += (fq < first) || (fq == first && aq < a);
+            }
+            kout[pos] = s_orig[a];
+        }
+    }
+    if (lane == 0) keep_counts[img] = nk;
+}
+
+}  // namespace yolo
+
+using namespace yolo;
+
+YOLO_API int yolo_decode(const float *pred, int N, int S, int B, int C, double conf_thr, double *rec, int32_t *counts, yolo_stream_t stream)
+{
+    if (!pred || !rec || !counts || N < 0 || S <= 0 || B <= 0 || C <= 0) return fail(YOLO_E_ARG, "yolo_decode: bad argument");
+    if (S * S * B > 1024 || B > 8) return fail(YOLO_E_UNSUPPORTED, "yolo_decode: S*S*B=%d > 1024 or B=%d > 8", S * S * B, B);
+    if (N == 0) return 0;
+    hipLaunchKernelGGL(decode_kernel, dim3(N), dim3(128), 0, STRM(stream), pred, S, B, C, conf_thr, rec, counts);
+    return check_launch("yolo_decode");
+}
+
+YOLO_API int yolo_decode_gt(const float *tgt, int N, int S, int B, int C, double *rec, int32_t *counts, yolo_stream_t stream)
+{
+    if (!tgt || !rec || !counts || N < 0 || S <= 0 || B <= 0 || C <= 0) return fail(YOLO_E_ARG, "yolo_decode_gt: bad argument");
+    if (S * S > 1024) return fail(YOLO_E_UNSUPPORTED, "yolo_decode_gt: S*S=%d > 1024", S * S);
+    if (N == 0) return 0;
+    hipLaunchKernelGGL(decode_gt_kernel, dim3(N), dim3(128), 0, STRM(stream), tgt, S, B, C, rec, counts);
+    return check_launch("yolo_decode_gt");
+}
+
+YOLO_API int yolo_nms(const double *rec, const int32_t *counts, int N, int max_per_img, double thr, int variant, int32_t *keep,
+                      int32_t *keep_counts, yolo_stream_t stream)
+{
+    if (!rec || !counts || !keep || !keep_counts || N < 0 || max_per_img <= 0) return fail(YOLO_E_ARG, "yolo_nms: bad argument");
+    if (max_per_img > 128) return fail(YOLO_E_UNSUPPORTED, "yolo_nms: max_per_img=%d > 128", max_per_img);
+    if (variant != YOLO_NMS_INFERENCE && variant != YOLO_NMS_METRICS) return fail(YOLO_E_ARG, "yolo_nms: variant %d", variant);
+    if (N == 0) return 0;
+    if (variant == YOLO_NMS_INFERENCE)
+        hipLaunchKernelGGL(nms_kernel<YOLO_NMS_INFERENCE>, dim3(N), dim3(64), 0, STRM(stream), rec, counts, max_per_img, thr, keep, keep_counts);
+    else
+        hipLaunchKernelGGL(nms_kernel<YOLO_NMS_METRICS>, dim3(N), dim3(64), 0, STRM(stream), rec, counts, max_per_img, thr, keep, keep_counts);
+    return check_launch("yolo_nms");
+}
+
+YOLO_API int yolo_pairwise_iou(const double *a, int na, const double *b, int nb, int variant, double *out, yolo_stream_t stream)
+{
+    if (!a || !b || !out || na < 0 || nb < 0) return fail(YOLO_E_ARG, "yolo_pairwise_iou: bad argument");
+    if (variant != YOLO_NMS_INFERENCE && variant != YOLO_NMS_METRICS) return fail(YOLO_E_ARG, "yolo_pairwise_iou: variant %d", variant);
+    const long total = (long)na * nb;
+    if (total == 0) return 0;
+    const int grid = (int)((total + 255) / 256);
+    if (variant == YOLO_NMS_INFERENCE)
+        hipLaunchKernelGGL(pairwise_iou_kernel<YOLO_NMS_INFERENCE>, dim3(grid), dim3(256), 0, STRM(stream), a, na, b, nb, out);
+    else
+        hipLaunchKernelGGL(pairwise_iou_kernel<YOLO_NMS_METRICS>, dim3(grid), dim3(256), 0, STRM(stream), a, na, b, nb, out);
+    return check_launch("yolo_pairwise_iou");
+}

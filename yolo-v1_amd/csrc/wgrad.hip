@@ -1,0 +1,257 @@
+// Weight-gradient kernel for gfx950:  dw[co][tap][ci] (+)= sum_p dy[p][co] * x[p + tapoff(tap)][ci]
+//
+// Both operands are K-strided for this product (the reduction index is the pixel, the contiguous
+// axis is the channel), so the tiles are staged pixel-major by LDS-DMA exactly as they lie in HBM
+// and the MFMA fragments are fetched with gfx950's transposing LDS read (ds_read_b64_tr_b16): no
+// transposed copy of an activation is ever written.
+//
+// "Flat" pixel indexing: p runs over EVERY pixel slot of the zero-haloed dy buffer (halo included).
+// dy is exactly zero on its halo, so those slots add nothing, and for a stride-1 conv the matching
+// input pixel of tap (ky,kx) is simply p + (ky-pad)*row_stride + (kx-pad): no div/mod, no bounds
+// checks, perfectly contiguous 16-B loads.  The price is (H+2)(W+2)/(HW) extra pixels (1.04x at
+// 112x112 .. 1.65x at 7x7).  A stride-2 conv runs on a zero-stuffed dy of the input's geometry.
+// Callers keep a guard band of zeros (>= row_stride+1 pixels) in front of and behind every
+// activation buffer so that shifted reads of halo slots stay inside the allocation.
+//
+// Tile: 128 co x 128 ci per (tap), 64 pixels per K step, 4 waves (2x2), v_mfma_f32_32x32x16_bf16.
+// Split over pixel ranges (blockIdx.y) with fp32 atomics into the packed gradient.
+// Replaces the weight-gradient half of aten convolution_backward / addmm backward for
+// src/yolo/models.py:47-84,239-245,313-332.
+#include "common.h"
+
+namespace yolo {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+__device__ uint4 g_zero_line[16];  // 256 B of zeros: source for out-of-range rows
+
+struct WgradParams {
+    const bf16_t *x;
+    const bf16_t *dy;
+    float *dw;
+    long P;                 // flat pixel slots to reduce over
+    long p_per_split;
+    int dy_px_stride, x_px_stride;
+    int Cout, Cin, Cout_ld, Cin_ld;  // logical sizes and loadable (multiple-of-8) widths
+    int KH, KW, pad;
+    long x_row_stride;
+    int n_co_tiles, n_ci_tiles, ntaps;
+    int atomic;
+};
+
+#define GLDS16(gptr, lptr) \
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gptr), (__attribute__((address_space(3))) void *)(lptr), 16, 0, 0)
+
+constexpr int WG_T = 128;                 // tile edge (co and ci)
+constexpr int WG_BP = 64;                 // pixels per K step
+constexpr int WG_TILE_BYTES = WG_BP * WG_T * 2;   // 16 KB
+constexpr int WG_STAGE_BYTES = 2 * WG_TILE_BYTES; // dy + x
+constexpr int WG_LDS_BYTES = 2 * WG_STAGE_BYTES;  // double buffered: 64 KB
+
+__global__ void __launch_bounds__(256, 2) wgrad_kernel(const WgradParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wco = wave >> 1, wci = wave & 1;
+
+    // XCD-aware remap (see igemm.hip): contiguous logical tiles per XCD
+    const int nwg = p.n_co_tiles * p.n_ci_tiles * p.ntaps;
+    int bid = blockIdx.x;
+    {
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, k = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+    }
+    // co-tile fastest, then ci-tile, then tap: neighbours share the x tile of one tap
+    const int co_tile = bid % p.n_co_tiles;
+    const int rest = bid / p.n_co_tiles;
+    const int ci_tile = rest % p.n_ci_tiles;
+    const int tap = rest / p.n_ci_tiles;
+    const int ky = tap / p.KW, kx = tap - ky * p.KW;
+    const long tap_off = (long)(ky - p.pad) * p.x_row_stride + (long)(kx - p.pad) * p.x_px_stride;
+    const int co0 = co_tile * WG_T, ci0 = ci_tile * WG_T;
+
+    const long pbeg = (long)blockIdx.y * p.p_per_split;
+    const long pend = min(p.P, pbeg + p.p_per_split);
+
+    // ---- LDS-DMA sources.  A wave-instruction covers 4 pixel rows x 256 B.  Slot (row, c') holds
+    // data chunk c = c' ^ ((row&3)<<2): the transposing reads of one 32-lane half then touch 16
+    // distinct 16-B slots of the 256-B bank row (conflict-free).
+    int row_of[4], a_coff[4], b_coff[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int pos = (i * 4 + wave) * 64 + lane;
+        const int row = pos >> 4, cs = pos & 15;
+        const int c = cs ^ ((row & 3) << 2);
+        row_of[i] = row;
+        int ca = co0 / 8 + c, cb = ci0 / 8 + c;
+        if (ca >= p.Cout_ld / 8) ca = p.Cout_ld / 8 - 1;
+        if (cb >= p.Cin_ld / 8) cb = p.Cin_ld / 8 - 1;
+        a_coff[i] = ca * 8;
+        b_coff[i] = cb * 8;
+    }
+    const bf16_t *zline = reinterpret_cast<const bf16_t *>(g_zero_line) + (lane & 15) * 8;
+
+    auto stage = [&](int buf, long pb) {
+        char *sb = smem + buf * WG_STAGE_BYTES;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const long pr = pb + row_of[i];
+            const bool ok = pr < pend;
+            const bf16_t *sa = ok ? p.dy + pr * p.dy_px_stride + a_coff[i] : zline;
+            const bf16_t *sx = ok ? p.x + pr * p.x_px_stride + tap_off + b_coff[i] : zline;
+            GLDS16(sa, sb + (i * 4 + wave) * 1024);
+            GLDS16(sx, sb + WG_TILE_BYTES + (i * 4 + wave) * 1024);
+        }
+    };
+
+    // ---- transposing fragment reads (see header): group g = lane>>4, q = (lane>>2)&3, pp = lane&3
+    const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
+    int a_rd[2], b_rd[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int row = (g >> 1) * 8 + q;
+        const int ca = (wco * 64 + t * 32 + (g & 1) * 16 + 4 * pp) >> 3;
+        const int cb = (wci * 64 + t * 32 + (g & 1) * 16 + 4 * pp) >> 3;
+        a_rd[t] = row * 256 + ((ca ^ ((row & 3) << 2)) << 4) + (pp & 1) * 8;
+        b_rd[t] = WG_TILE_BYTES + row * 256 + ((cb ^ ((row & 3) << 2)) << 4) + (pp & 1) * 8;
+    }
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    typedef __attribute__((address_space(3))) s16x4 *lds_s16x4;
+    if (pbeg < pend) stage(0, pbeg);
+    int it = 0;
+    for (long pb = pbeg; pb < pend; pb += WG_BP, ++it) {
+        const int buf = it & 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (pb + WG_BP < pend) stage(buf ^ 1, pb + WG_BP);
+        char *sb = smem + buf * WG_STAGE_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < WG_BP / 16; ++ks) {
+            bf16x8 af[2], bfr[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(sb + a_rd[t] + ks * 4096));
+                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(sb + a_rd[t] + ks * 4096 + 1024));
+                af[t] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+            }
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(sb + b_rd[t] + ks * 4096));
+                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(sb + b_rd[t] + ks * 4096 + 1024));
+                bfr[t] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+        }
+    }
+
+    // ---- output: D row (= co) = (reg&3) + 8*(reg>>2) + 4*(lane>>5), col (= ci) = lane&31.
+    // Per register the 32 lanes of a half write 128 contiguous bytes of one dw row.
+    const long ldw = (long)p.ntaps * p.Cin;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int ci = ci0 + wci * 64 + j * 32 + (lane & 31);
+            if (ci >= p.Cin) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = co0 + wco * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (co >= p.Cout) continue;
+                float *o = p.dw + (long)co * ldw + (long)tap * p.Cin + ci;
+                if (p.atomic) atomicAdd(o, acc[i][j][r]);
+                else *o = acc[i][j][r];
+            }
+        }
+}
+
+// db[c] += sum_p dy[p][c]  (bias gradient): each workgroup sums a slab of pixels for 8*64 channels
+__global__ void __launch_bounds__(256) colsum_kernel(const bf16_t *__restrict__ dy, long P, int px_stride, int C, long p_per_blk, float *__restrict__ db)
+{
+    const int c8 = blockIdx.x * 64 + (threadIdx.x & 63);  // 8-channel chunk
+    const int sub = threadIdx.x >> 6;                      // 4 pixel phases
+    const long pbeg = (long)blockIdx.y * p_per_blk, pend = min(P, pbeg + p_per_blk);
+    float s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (c8 * 8 < C) {
+        for (long pr = pbeg + sub; pr < pend; pr += 4) {
+            const uint4 v = *reinterpret_cast<const uint4 *>(dy + pr * px_stride + c8 * 8);
+            s[0] += __uint_as_float(v.x << 16); s[1] += __uint_as_float(v.x & 0xffff0000u);
+            s[2] += __uint_as_float(v.y << 16); s[3] += __uint_as_float(v.y & 0xffff0000u);
+            s[4] += __uint_as_float(v.z << 16); s[5] += __uint_as_float(v.z & 0xffff0000u);
+            s[6] += __uint_as_float(v.w << 16); s[7] += __uint_as_float(v.w & 0xffff0000u);
+        }
+    }
+    __shared__ float red[4][64][9];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) red[sub][threadIdx.x & 63][k] = s[k];
+    __syncthreads();
+    if (sub == 0 && c8 * 8 < C) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const float t = red[0][threadIdx.x][k] + red[1][threadIdx.x][k] + red[2][threadIdx.x][k] + red[3][threadIdx.x][k];
+            if (c8 * 8 + k < C) atomicAdd(db + c8 * 8 + k, t);
+        }
+    }
+}
+
+}  // namespace yolo
+
+using namespace yolo;
+
+YOLO_API int yolo_wgrad(const yolo_wgrad_desc *d, const void *x, const void *dy, float *dw, float *db, yolo_stream_t stream)
+{
+    if (!d || !x || !dy || (!dw && !db)) return fail(YOLO_E_ARG, "yolo_wgrad: null pointer");
+    if (d->P <= 0 || d->Cout <= 0 || d->Cin <= 0 || d->KH <= 0 || d->KW <= 0 || d->split <= 0) return fail(YOLO_E_ARG, "yolo_wgrad: bad descriptor");
+    if ((d->dy_px_stride & 7) || (d->x_px_stride & 7) || (d->x_row_stride & 7) || d->dy_px_stride < d->Cout || d->x_px_stride < d->Cin)
+        return fail(YOLO_E_UNSUPPORTED, "yolo_wgrad: pixel strides must be multiples of 8 elements and cover the channels");
+    hipStream_t s = STRM(stream);
+    if (dw) {
+        static bool attr_done = false;
+        if (!attr_done) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&wgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, WG_LDS_BYTES);
+            if (e != hipSuccess) return fail((int)e, "yolo_wgrad: hipFuncSetAttribute: %s", hipGetErrorString(e));
+            attr_done = true;
+        }
+        WgradParams p{};
+        p.x = (const bf16_t *)x; p.dy = (const bf16_t *)dy; p.dw = dw;
+        p.P = d->P;
+        p.dy_px_stride = d->dy_px_stride; p.x_px_stride = d->x_px_stride;
+        p.Cout = d->Cout; p.Cin = d->Cin;
+        p.Cout_ld = (int)((std::min<long>(d->dy_px_stride, ((long)d->Cout + 7) & ~7L)));
+        p.Cin_ld = (int)((std::min<long>(d->x_px_stride, ((long)d->Cin + 7) & ~7L)));
+        p.KH = d->KH; p.KW = d->KW; p.pad = d->pad; p.x_row_stride = d->x_row_stride;
+        p.n_co_tiles = (d->Cout + WG_T - 1) / WG_T;
+        p.n_ci_tiles = (d->Cin + WG_T - 1) / WG_T;
+        p.ntaps = d->KH * d->KW;
+        long per = (d->P + d->split - 1) / d->split;
+        per = (per + WG_BP - 1) / WG_BP * WG_BP;
+        const int splits = (int)((d->P + per - 1) / per);
+        p.p_per_split = per;
+        p.atomic = (splits > 1 || d->accumulate) ? 1 : 0;
+        hipLaunchKernelGGL(wgrad_kernel, dim3(p.n_co_tiles * p.n_ci_tiles * p.ntaps, splits), dim3(256), WG_LDS_BYTES, s, p);
+        if (int rc = check_launch("yolo_wgrad")) return rc;
+    }
+    if (db) {
+        const int chunks = (d->Cout + 7) / 8;
+        const int gx = (chunks + 63) / 64;
+        int gy = (int)std::min<long>(1024, (d->P + 255) / 256);
+        if (gy < 1) gy = 1;
+        const long per = (d->P + gy - 1) / gy;
+        hipLaunchKernelGGL(colsum_kernel, dim3(gx, gy), dim3(256), 0, s, (const bf16_t *)dy, (long)d->P, d->dy_px_stride, d->Cout, per, db);
+        if (int rc = check_launch("yolo_wgrad(bias)")) return rc;
+    }
+    return 0;
+}

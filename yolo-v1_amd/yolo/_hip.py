@@ -1,0 +1,133 @@
+"""ctypes binding of libyolo_hip.so (include/yolo_hip.h) -- the only way Python reaches the GPU kernels.
+
+The library is hand-written HIP for gfx950, built in-tree by ``make -C yolo-v1_amd/csrc`` (or
+``__graft_entry__.build()``).  There is NO fallback: if a CUDA/ROCm tensor reaches a module of this
+package and the library is missing, :func:`lib` raises.
+"""
+
+from __future__ import annotations
+
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libyolo_hip.so")
+_LIB = None
+
+c_int, c_long, c_float, c_double, c_void_p = ctypes.c_int, ctypes.c_long, ctypes.c_float, ctypes.c_double, ctypes.c_void_p
+
+
+class IgemmDesc(ctypes.Structure):
+    """struct yolo_igemm_desc (include/yolo_hip.h)."""
+
+    _fields_ = [
+        ("N", ctypes.c_int32), ("Ho", ctypes.c_int32), ("Wo", ctypes.c_int32),
+        ("in_img_stride", ctypes.c_int64),
+        ("in_row_stride", ctypes.c_int32), ("in_px_stride", ctypes.c_int32), ("in_off", ctypes.c_int32),
+        ("stride", ctypes.c_int32), ("KH", ctypes.c_int32), ("KW", ctypes.c_int32),
+        ("tap_len", ctypes.c_int32), ("Cout", ctypes.c_int32),
+        ("out_img_stride", ctypes.c_int64),
+        ("out_row_stride", ctypes.c_int32), ("out_px_stride", ctypes.c_int32), ("out_off", ctypes.c_int32),
+        ("epilogue", ctypes.c_int32), ("slope", ctypes.c_float), ("out_fp32", ctypes.c_int32), ("split_k", ctypes.c_int32),
+        ("aux_img_stride", ctypes.c_int64),
+        ("aux_row_stride", ctypes.c_int32), ("aux_px_stride", ctypes.c_int32), ("aux_off", ctypes.c_int32),
+    ]
+
+
+class WgradDesc(ctypes.Structure):
+    """struct yolo_wgrad_desc (include/yolo_hip.h)."""
+
+    _fields_ = [
+        ("P", ctypes.c_int64),
+        ("dy_px_stride", ctypes.c_int32), ("x_px_stride", ctypes.c_int32),
+        ("Cout", ctypes.c_int32), ("Cin", ctypes.c_int32),
+        ("KH", ctypes.c_int32), ("KW", ctypes.c_int32), ("pad", ctypes.c_int32),
+        ("x_row_stride", ctypes.c_int64),
+        ("split", ctypes.c_int32), ("accumulate", ctypes.c_int32),
+    ]
+
+
+class PoolDesc(ctypes.Structure):
+    """struct yolo_pool_desc (include/yolo_hip.h)."""
+
+    _fields_ = [("N", ctypes.c_int32), ("H", ctypes.c_int32), ("W", ctypes.c_int32), ("C", ctypes.c_int32),
+                ("in_halo", ctypes.c_int32), ("out_halo", ctypes.c_int32)]
+
+
+EPI_NONE, EPI_BIAS, EPI_BIAS_LRELU, EPI_MUL_DLRELU = 0, 1, 2, 3
+NMS_INFERENCE, NMS_METRICS = 0, 1
+
+# name -> argtypes ; every symbol include/yolo_hip.h declares (tests check the list against the header)
+_SIGS = {
+    "yolo_hip_abi_version": [],
+    "yolo_decode": [c_void_p, c_int, c_int, c_int, c_int, c_double, c_void_p, c_void_p, c_void_p],
+    "yolo_decode_gt": [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p],
+    "yolo_nms": [c_void_p, c_void_p, c_int, c_int, c_double, c_int, c_void_p, c_void_p, c_void_p],
+    "yolo_pairwise_iou": [c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p],
+    "yolo_loss_fwd_bwd": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p],
+    "yolo_loss_iou": [c_void_p, c_void_p, c_long, c_void_p, c_void_p],
+    "yolo_igemm": [ctypes.POINTER(IgemmDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
+    "yolo_wgrad": [ctypes.POINTER(WgradDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
+    "yolo_maxpool2_fwd": [ctypes.POINTER(PoolDesc), c_void_p, c_void_p, c_void_p],
+    "yolo_maxpool2_bwd_lrelu": [ctypes.POINTER(PoolDesc), c_void_p, c_void_p, c_float, c_void_p, c_void_p],
+    "yolo_nchw_f32_to_nhwc_bf16": [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p],
+    "yolo_nhwc_bf16_to_nchw_f32": [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p],
+    "yolo_nhwc_bf16_to_nchw_bf16": [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p],
+    "yolo_scale_rows_to_bf16": [c_void_p, c_void_p, c_float, c_void_p, c_float, c_int, c_int, c_int, c_void_p, c_void_p],
+    "yolo_dropout_bf16": [c_void_p, c_void_p, c_float, c_long, c_void_p, c_void_p],
+    "yolo_pack_conv_weight": [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p],
+    "yolo_pack_fc_weight": [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p],
+    "yolo_unpack_conv_wgrad": [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p],
+    "yolo_im2col_rows": [c_void_p, c_long, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p],
+    "yolo_transpose_f32_to_bf16": [c_void_p, c_int, c_int, c_void_p, c_int, c_void_p],
+    "yolo_cast_f32_to_bf16": [c_void_p, c_long, c_void_p, c_void_p],
+    "yolo_cast_bf16_to_f32": [c_void_p, c_long, c_void_p, c_void_p],
+    "yolo_bias_lrelu_rows": [c_void_p, c_void_p, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p],
+}
+
+
+def available() -> bool:
+    return os.path.exists(LIB_PATH)
+
+
+def lib():
+    """Load libyolo_hip.so once.  Raises (never falls back) when it is missing."""
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} not found: the gfx950 HIP library is not built (run `make -C yolo-v1_amd/csrc` or "
+                "`python -c 'import __graft_entry__ as g; g.build()'`).  This package has no CPU/eager fallback for GPU tensors.")
+        L = ctypes.CDLL(LIB_PATH)
+        for name, args in _SIGS.items():
+            fn = getattr(L, name)  # AttributeError if the library lacks a declared symbol
+            fn.argtypes = args
+            fn.restype = c_int
+        L.yolo_hip_last_error.argtypes = []
+        L.yolo_hip_last_error.restype = ctypes.c_char_p
+        _LIB = L
+    return _LIB
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = lib().yolo_hip_last_error().decode(errors="replace")
+        raise RuntimeError(f"libyolo_hip {what} failed (code {rc}): {msg}")
+
+
+def ptr(t) -> c_void_p:
+    """Device pointer of a tensor (None -> NULL)."""
+    return c_void_p(None) if t is None else c_void_p(t.data_ptr())
+
+
+def stream() -> c_void_p:
+    """The current PyTorch HIP stream as hipStream_t."""
+    return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def require_cuda(*tensors) -> None:
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("libyolo_hip kernels need device tensors (got a CPU tensor)")

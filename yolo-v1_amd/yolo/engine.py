@@ -1,0 +1,562 @@
+"""Layer-plan executor: runs a conv / pool / FC stack of the reference's models on the HIP kernels.
+
+A *plan* is built once from the PyTorch-layout modules (``nn.Conv2d``/``nn.LeakyReLU``/``nn.MaxPool2d``
+inside ``backbone.features`` / ``head`` -- those modules stay the owners of the fp32 parameters so
+that ``state_dict`` keys and shapes are the reference's).  On a device tensor the
+modules' ``forward`` is bypassed and the plan drives libyolo_hip.so:
+
+  * activations: zero-haloed NHWC bf16 buffers with a guard band (``Act``), allocated once per
+    (batch, mode) and reused; producers only ever write the interior, so halos stay zero;
+  * weights: bf16 panels re-packed from the fp32 masters only when a parameter's version changes;
+  * forward = one yolo_igemm per conv / Linear (+ pool / flatten helpers);
+  * backward = per conv one yolo_wgrad (flat pixel indexing) + one yolo_igemm data-gradient whose
+    epilogue applies the previous LeakyReLU's derivative (or a pool backward).
+
+Everything is enqueued on the current PyTorch stream; there is no host synchronisation.
+"""
+
+from __future__ import annotations
+
+import ctypes
+from dataclasses import dataclass, field
+
+import torch
+import torch.nn as nn
+
+from . import _hip
+from ._hip import (EPI_BIAS, EPI_BIAS_LRELU, EPI_MUL_DLRELU, EPI_NONE, IgemmDesc, PoolDesc, WgradDesc, check, lib, ptr, stream)
+
+
+def _round_up(a: int, b: int) -> int:
+    return (a + b - 1) // b * b
+
+
+class Act:
+    """Zero-haloed NHWC bf16 activation: [N][H+2h][W+2h][C] plus guard bands of zeros."""
+
+    def __init__(self, N, H, W, C, halo, device, halo_hi=None):
+        self.N, self.H, self.W, self.C = N, H, W, C
+        self.halo = halo
+        self.halo_hi = halo if halo_hi is None else halo_hi
+        self.Hp = H + self.halo + self.halo_hi
+        self.Wp = W + self.halo + self.halo_hi
+        self.px_stride = C
+        self.row_stride = self.Wp * C
+        self.img_stride = self.Hp * self.Wp * C
+        self.slots = N * self.Hp * self.Wp
+        guard = _round_up((self.Wp + 2) * C + 64 * 8, 128)
+        self.store = torch.zeros(guard + self.slots * C + guard, dtype=torch.bfloat16, device=device)
+        self.t = self.store[guard: guard + self.slots * C]
+
+    @property
+    def p(self):
+        return ctypes.c_void_p(self.t.data_ptr())
+
+    def interior_off(self, shift=0):
+        """element offset of logical pixel (-shift, -shift) inside an image"""
+        h = self.halo - shift
+        return (h * self.Wp + h) * self.C
+
+    def view(self):
+        return self.t.view(self.N, self.Hp, self.Wp, self.C)
+
+    def interior(self):
+        h = self.halo
+        return self.view()[:, h: h + self.H, h: h + self.W, :]
+
+
+@dataclass
+class Layer:
+    kind: str                      # conv | pool | flatten | fc
+    name: str = ""
+    Cout: int = 0
+    Cin: int = 0
+    K: int = 1
+    stride: int = 1
+    pad: int = 0
+    lrelu: bool = False
+    dropout: float = 0.0
+    weight: nn.Parameter | None = None
+    bias: nn.Parameter | None = None
+    first: bool = False            # the 3-channel 7x7/s2 stem (NHWC4 input, row-segment taps)
+    # geometry, filled by Plan._shape
+    Hin: int = 0
+    Win: int = 0
+    Hout: int = 0
+    Wout: int = 0
+
+
+class Plan:
+    """Executable plan for [conv|pool]* [flatten fc*]? ."""
+
+    SLOPE = 0.1
+
+    def __init__(self, layers: list[Layer], in_channels: int, input_is_image: bool, S: int | None = None):
+        self.layers = layers
+        self.in_channels = in_channels
+        self.input_is_image = input_is_image
+        self.params: list[nn.Parameter] = []
+        for L in layers:
+            if L.kind in ("conv", "fc"):
+                self.params += [L.weight, L.bias]
+        self._packed: dict[int, tuple] = {}
+        self._ws: dict[tuple, list] = {}
+
+    # ------------------------------------------------------------------ construction helpers
+    @staticmethod
+    def from_modules(mods, in_channels: int, input_is_image: bool) -> "Plan":
+        """mods: flat list of nn.Module (Conv2d, LeakyReLU, MaxPool2d, Flatten, Linear, Dropout)."""
+        layers: list[Layer] = []
+        i = 0
+        mods = list(mods)
+        while i < len(mods):
+            m = mods[i]
+            nxt = mods[i + 1] if i + 1 < len(mods) else None
+            if isinstance(m, nn.Conv2d):
+                k, s, p = m.kernel_size[0], m.stride[0], m.padding[0]
+                if m.kernel_size[0] != m.kernel_size[1] or m.groups != 1 or m.dilation != (1, 1) or m.bias is None:
+                    raise ValueError(f"unsupported conv {m}")
+                act = isinstance(nxt, nn.LeakyReLU)
+                if act and abs(nxt.negative_slope - Plan.SLOPE) > 1e-12:
+                    raise ValueError("only LeakyReLU(0.1) is fused")
+                first = (m.in_channels == 3 and k == 7 and s == 2 and p == 3)
+                if not first and not ((k == 3 and p == 1) or (k == 1 and p == 0)) or (not first and s not in (1, 2)):
+                    raise ValueError(f"unsupported conv geometry {m}")
+                if not first and (m.in_channels % 32 or m.out_channels % 8):
+                    raise ValueError(f"unsupported channel counts {m}")
+                layers.append(Layer("conv", Cout=m.out_channels, Cin=m.in_channels, K=k, stride=s, pad=p, lrelu=act,
+                                    weight=m.weight, bias=m.bias, first=first))
+                i += 2 if act else 1
+            elif isinstance(m, nn.MaxPool2d):
+                ks = m.kernel_size if isinstance(m.kernel_size, int) else m.kernel_size[0]
+                st = m.stride if isinstance(m.stride, int) else m.stride[0]
+                if ks != 2 or st != 2:
+                    raise ValueError("only MaxPool2d(2,2)")
+                layers.append(Layer("pool"))
+                i += 1
+            elif isinstance(m, nn.Flatten):
+                layers.append(Layer("flatten"))
+                i += 1
+            elif isinstance(m, nn.Linear):
+                act = isinstance(nxt, nn.LeakyReLU)
+                j = i + (2 if act else 1)
+                drop = 0.0
+                if j < len(mods) and isinstance(mods[j], nn.Dropout):
+                    drop = mods[j].p
+                    j += 1
+                layers.append(Layer("fc", Cout=m.out_features, Cin=m.in_features, lrelu=act, dropout=drop, weight=m.weight, bias=m.bias))
+                i = j
+            else:
+                raise ValueError(f"unsupported module in plan: {m}")
+        return Plan(layers, in_channels, input_is_image)
+
+    # ------------------------------------------------------------------ weights
+    def _pack(self, li: int, need_dgrad: bool):
+        L = self.layers[li]
+        w = L.weight
+        key = (w._version, w.data_ptr(), need_dgrad)
+        hit = self._packed.get(li)
+        if hit is not None and hit[0][0] == key[0] and hit[0][1] == key[1] and (hit[0][2] or not need_dgrad):
+            return hit[1], hit[2]
+        dev = w.device
+        wd = None
+        wsrc = w.detach()
+        if wsrc.dtype != torch.float32 or not wsrc.is_contiguous():
+            wsrc = wsrc.float().contiguous()
+        if L.kind == "conv":
+            if L.first:
+                wf = torch.empty((L.Cout, 7, 8, 4), dtype=torch.bfloat16, device=dev)
+                check(lib().yolo_pack_conv_weight(ptr(wsrc), L.Cout, 3, 7, 7, 4, 8, ptr(wf), None, stream()), "pack_conv_weight")
+            else:
+                wf = torch.empty((L.Cout, L.K, L.K, L.Cin), dtype=torch.bfloat16, device=dev)
+                if need_dgrad:
+                    wd = torch.empty((L.Cin, L.K, L.K, L.Cout), dtype=torch.bfloat16, device=dev)
+                check(lib().yolo_pack_conv_weight(ptr(wsrc), L.Cout, L.Cin, L.K, L.K, L.Cin, L.K, ptr(wf), ptr(wd), stream()), "pack_conv_weight")
+        else:
+            wf = torch.empty((L.Cout, L.Cin), dtype=torch.bfloat16, device=dev)
+            check(lib().yolo_cast_f32_to_bf16(ptr(wsrc), wsrc.numel(), ptr(wf), stream()), "cast")
+            if need_dgrad:
+                ld = _round_up(L.Cout, 32)
+                wd = torch.zeros((L.Cin, ld), dtype=torch.bfloat16, device=dev)
+                check(lib().yolo_transpose_f32_to_bf16(ptr(wsrc), L.Cout, L.Cin, ptr(wd), ld, stream()), "transpose")
+        self._packed[li] = (key, wf, wd)
+        return wf, wd
+
+    # ------------------------------------------------------------------ workspace
+    def _workspace(self, N: int, x_shape, device, train: bool):
+        key = (N, tuple(x_shape[1:]), str(device), train)
+        pool = self._ws.setdefault(key, [])
+        if pool:
+            return key, pool.pop()
+        ws = {"acts": [], "grads": {}, "misc": {}}
+        C, H, W = x_shape[1], x_shape[2], x_shape[3]
+        if self.layers and self.layers[0].kind == "conv" and self.layers[0].first:
+            a = Act(N, H, W, 4, 3, device)
+        else:
+            a = Act(N, H, W, C, 1, device)
+        ws["in"] = a
+        cur = a
+        flat = None
+        for li, L in enumerate(self.layers):
+            if L.kind == "conv":
+                L.Hin, L.Win = cur.H, cur.W
+                L.Hout = (cur.H + 2 * L.pad - L.K) // L.stride + 1
+                L.Wout = (cur.W + 2 * L.pad - L.K) // L.stride + 1
+                cur = Act(N, L.Hout, L.Wout, L.Cout, 1, device)
+            elif L.kind == "pool":
+                L.Hin, L.Win = cur.H, cur.W
+                cur = Act(N, cur.H // 2, cur.W // 2, cur.C, 1, device)
+            elif L.kind == "flatten":
+                flat = torch.empty((N, cur.C * cur.H * cur.W), dtype=torch.bfloat16, device=device)
+                cur = flat
+            elif L.kind == "fc":
+                cur = None  # allocated per call (tiny)
+            ws["acts"].append(cur)
+        return key, ws
+
+    def _release(self, key, ws):
+        self._ws.setdefault(key, []).append(ws)
+
+    # ------------------------------------------------------------------ descriptors
+    def _conv_desc(self, L: Layer, a_in: Act, a_out: Act) -> IgemmDesc:
+        d = IgemmDesc()
+        d.N, d.Ho, d.Wo = a_in.N, L.Hout, L.Wout
+        d.in_img_stride, d.in_row_stride, d.in_px_stride = a_in.img_stride, a_in.row_stride, a_in.px_stride
+        d.stride = L.stride
+        if L.first:
+            d.in_off = 0
+            d.KH, d.KW, d.tap_len = 7, 1, 32
+        else:
+            d.in_off = a_in.interior_off(L.pad)
+            d.KH, d.KW, d.tap_len = L.K, L.K, L.Cin
+        d.Cout = L.Cout
+        d.out_img_stride, d.out_row_stride, d.out_px_stride = a_out.img_stride, a_out.row_stride, a_out.px_stride
+        d.out_off = a_out.interior_off()
+        d.epilogue = EPI_BIAS_LRELU if L.lrelu else EPI_BIAS
+        d.slope = self.SLOPE
+        d.out_fp32 = 0
+        d.split_k = 1
+        return d
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, x: torch.Tensor, train: bool, drop_training: bool):
+        """x: NCHW fp32 device tensor.  Returns (out, saved) -- out is (N, O) fp32 if the plan ends
+        with an fc layer, else NCHW fp32 features."""
+        L_ = lib()
+        st = stream()
+        N = x.shape[0]
+        dev = x.device
+        x = x.detach()
+        if x.dtype != torch.float32 or not x.is_contiguous():
+            x = x.float().contiguous()
+        key, ws = self._workspace(N, x.shape, dev, train)
+        a = ws["in"]
+        if a.C == 4 and a.halo == 3:
+            check(L_.yolo_nchw_f32_to_nhwc_bf16(ptr(x), N, x.shape[1], x.shape[2], x.shape[3], a.p, 4, 3, 3, st), "nchw->nhwc4")
+        else:
+            check(L_.yolo_nchw_f32_to_nhwc_bf16(ptr(x), N, x.shape[1], x.shape[2], x.shape[3], a.p, a.C, 1, 1, st), "nchw->nhwc")
+        cur = a
+        fc_saved = {}
+        out = None
+        for li, L in enumerate(self.layers):
+            nxt = ws["acts"][li]
+            if L.kind == "conv":
+                wf, _ = self._pack(li, train)
+                d = self._conv_desc(L, cur, nxt)
+                b = L.bias.detach()
+                check(L_.yolo_igemm(ctypes.byref(d), cur.p, ptr(wf), ptr(b), None, nxt.p, st), f"igemm conv{li}")
+                cur = nxt
+            elif L.kind == "pool":
+                pd = PoolDesc(N, cur.H, cur.W, cur.C, cur.halo, nxt.halo)
+                check(L_.yolo_maxpool2_fwd(ctypes.byref(pd), cur.p, nxt.p, st), "maxpool")
+                cur = nxt
+            elif L.kind == "flatten":
+                check(L_.yolo_nhwc_bf16_to_nchw_bf16(cur.p, N, cur.C, cur.H, cur.W, cur.halo, ptr(nxt), st), "flatten")
+                cur = nxt
+            elif L.kind == "fc":
+                wf, _ = self._pack(li, train)
+                xin = cur  # (N, K) bf16
+                K = L.Cin
+                d = IgemmDesc()
+                d.N, d.Ho, d.Wo = N, 1, 1
+                d.in_img_stride, d.in_row_stride, d.in_px_stride, d.in_off = xin.shape[1], 0, xin.shape[1], 0
+                d.stride, d.KH, d.KW, d.tap_len, d.Cout = 1, 1, 1, K, L.Cout
+                d.out_img_stride, d.out_row_stride, d.out_px_stride, d.out_off = L.Cout, 0, L.Cout, 0
+                d.slope = self.SLOPE
+                d.out_fp32 = 1
+                last = (li == len(self.layers) - 1)
+                nk = K // 64
+                splits = max(1, min(32, nk // 16)) if K >= 4096 else 1
+                b = L.bias.detach()
+                if splits > 1:
+                    acc = torch.zeros((N, L.Cout), dtype=torch.float32, device=dev)
+                    d.epilogue, d.split_k = EPI_NONE, splits
+                    check(L_.yolo_igemm(ctypes.byref(d), ptr(xin), ptr(wf), None, None, ptr(acc), st), f"igemm fc{li}")
+                    yb = torch.empty((N, L.Cout), dtype=torch.bfloat16, device=dev) if not last else None
+                    yf = torch.empty((N, L.Cout), dtype=torch.float32, device=dev) if last else None
+                    check(L_.yolo_bias_lrelu_rows(ptr(acc), ptr(b), N, L.Cout, self.SLOPE if L.lrelu else 1.0, ptr(yb), ptr(yf), st), "bias_lrelu_rows")
+                else:
+                    yf = torch.empty((N, L.Cout), dtype=torch.float32, device=dev)
+                    d.epilogue, d.split_k = (EPI_BIAS_LRELU if L.lrelu else EPI_BIAS), 1
+                    check(L_.yolo_igemm(ctypes.byref(d), ptr(xin), ptr(wf), ptr(b), None, ptr(yf), st), f"igemm fc{li}")
+                    yb = None
+                    if not last:
+                        yb = torch.empty((N, L.Cout), dtype=torch.bfloat16, device=dev)
+                        check(L_.yolo_cast_f32_to_bf16(ptr(yf), yf.numel(), ptr(yb), st), "cast")
+                mask = None
+                y_act = yb
+                if not last and L.dropout > 0 and drop_training:
+                    mask = (torch.rand((N, L.Cout), device=dev) >= L.dropout).to(torch.uint8)
+                    yd = torch.empty_like(yb)
+                    check(L_.yolo_dropout_bf16(ptr(yb), ptr(mask), 1.0 / (1.0 - L.dropout), yb.numel(), ptr(yd), st), "dropout")
+                    cur = yd
+                else:
+                    cur = yb
+                fc_saved[li] = (xin, y_act, mask)
+                if last:
+                    out = yf
+        if out is None:
+            out = torch.empty((N, cur.C, cur.H, cur.W), dtype=torch.float32, device=dev)
+            check(L_.yolo_nhwc_bf16_to_nchw_f32(cur.p, N, cur.C, cur.H, cur.W, cur.halo, ptr(out), st), "nhwc->nchw")
+        saved = (key, ws, fc_saved, N, dev) if train else None
+        if not train:
+            self._release(key, ws)
+        return out, saved
+
+    # ------------------------------------------------------------------ backward
+    def _grad_buf(self, ws, li: int, N, dev) -> Act:
+        """gradient wrt the (post-activation-derivative) output of conv layer li, in the geometry
+        yolo_wgrad's flat indexing needs (= the layer's INPUT geometry; zero-stuffed for stride 2)."""
+        g = ws["grads"].get(li)
+        if g is None:
+            L = self.layers[li]
+            if L.stride == 1 or L.first:
+                g = Act(N, L.Hout, L.Wout, L.Cout, 1, dev)
+            else:
+                g = Act(N, L.Hin, L.Win, L.Cout, 1, dev)
+            ws["grads"][li] = g
+        return g
+
+    def _grad_out_strides(self, L: Layer, g: Act):
+        """(img, row, px, off) strides a producer uses to write layer L's output gradient into g."""
+        if L.stride == 1 or L.first:
+            return g.img_stride, g.row_stride, g.px_stride, g.interior_off()
+        return g.img_stride, 2 * g.row_stride, 2 * g.px_stride, g.interior_off()
+
+    def backward(self, saved, gout: torch.Tensor, need_gx: bool):
+        """gout: gradient of the plan output (same shape as forward's out).  Returns (gx or None, [param grads])."""
+        L_ = lib()
+        st = stream()
+        key, ws, fc_saved, N, dev = saved
+        grads: dict[int, tuple] = {}
+        nl = len(self.layers)
+        gout = gout.detach()
+        if gout.dtype != torch.float32 or not gout.is_contiguous():
+            gout = gout.float().contiguous()
+
+        # what each layer's input activation is
+        def input_of(li):
+            return ws["in"] if li == 0 else ws["acts"][li - 1]
+
+        # g_cur: gradient flowing into the output of layer li (representation depends on kind)
+        g_flat = None       # fp32 (N, K) gradient wrt an fc layer's output / flatten output
+        g_act: Act | None = None   # Act gradient wrt a conv/pool output (already through LeakyReLU')
+        li = nl - 1
+        if self.layers[li].kind == "fc":
+            g_flat = gout.reshape(N, -1)
+        else:
+            # plan ends with conv features (NCHW fp32 gradient); last layer must be a conv (+lrelu)
+            L = self.layers[li]
+            assert L.kind == "conv", "plans end with fc or conv"
+            y = ws["acts"][li]
+            graw = Act(N, y.H, y.W, y.C, 1, dev)
+            check(L_.yolo_nchw_f32_to_nhwc_bf16(ptr(gout), N, y.C, y.H, y.W, graw.p, y.C, 1, 1, st), "gout->nhwc")
+            g = self._grad_buf(ws, li, N, dev)
+            self._apply_dlrelu_into(graw, y, L, g, st)
+            g_act = g
+
+        while li >= 0:
+            L = self.layers[li]
+            if L.kind == "fc":
+                xin, y_act, mask = fc_saved[li]
+                last = (li == nl - 1)
+                ldg = _round_up(L.Cout, 32)
+                gb = torch.empty((N, ldg), dtype=torch.bfloat16, device=dev)
+                # through dropout + LeakyReLU of THIS layer's output (none for the last layer)
+                check(L_.yolo_scale_rows_to_bf16(ptr(g_flat), ptr(mask), (1.0 / (1.0 - L.dropout)) if mask is not None else 1.0,
+                                                 ptr(y_act) if (L.lrelu and not last) else None, self.SLOPE, N, L.Cout, ldg, ptr(gb), st), "scale_rows")
+                # weight / bias gradient, native [O][K] layout
+                dw = torch.empty_like(L.weight, dtype=torch.float32)
+                db = torch.zeros_like(L.bias, dtype=torch.float32)
+                wd = WgradDesc(N, ldg, L.Cin, L.Cout, L.Cin, 1, 1, 0, 0, 1, 0)
+                check(L_.yolo_wgrad(ctypes.byref(wd), ptr(xin), ptr(gb), ptr(dw), ptr(db), st), f"wgrad fc{li}")
+                grads[li] = (dw, db)
+                # data gradient -> fp32 (N, K)
+                need_prev = li > 0 or need_gx
+                if need_prev:
+                    _, wt = self._pack(li, True)
+                    d = IgemmDesc()
+                    d.N, d.Ho, d.Wo = N, 1, 1
+                    d.in_img_stride, d.in_row_stride, d.in_px_stride, d.in_off = ldg, 0, ldg, 0
+                    d.stride, d.KH, d.KW, d.tap_len, d.Cout = 1, 1, 1, ldg, L.Cin
+                    d.out_img_stride, d.out_row_stride, d.out_px_stride, d.out_off = L.Cin, 0, L.Cin, 0
+                    d.epilogue, d.slope, d.out_fp32, d.split_k = EPI_NONE, self.SLOPE, 1, 1
+                    aux = None
+                    if li >= 2 and self.layers[li - 1].kind == "flatten" and self.layers[li - 2].kind == "conv" and self.layers[li - 2].lrelu:
+                        # LeakyReLU' of the conv in front of nn.Flatten, read from the flattened activation itself
+                        d.epilogue = EPI_MUL_DLRELU
+                        d.aux_img_stride, d.aux_row_stride, d.aux_px_stride, d.aux_off = L.Cin, 0, L.Cin, 0
+                        aux = ptr(xin)
+                    gprev = torch.empty((N, L.Cin), dtype=torch.float32, device=dev)
+                    check(L_.yolo_igemm(ctypes.byref(d), ptr(gb), ptr(wt), None, aux, ptr(gprev), st), f"dgrad fc{li}")
+                    g_flat = gprev
+                li -= 1
+            elif L.kind == "flatten":
+                # g_flat is the NCHW-flatten gradient of the conv stack's output (pre LeakyReLU')
+                y = input_of(li)  # Act of the last conv
+                lc = li - 1
+                Lc = self.layers[lc]
+                if Lc.kind == "conv" and Lc.stride == 1:
+                    # LeakyReLU' was already applied by the fc data-gradient epilogue
+                    g = self._grad_buf(ws, lc, N, dev)
+                else:
+                    g = ws["misc"].get("graw_flat")
+                    if g is None:
+                        g = Act(N, y.H, y.W, y.C, 1, dev)
+                        ws["misc"]["graw_flat"] = g
+                    assert Lc.kind == "pool", "nn.Flatten is expected after a stride-1 conv or a pool"
+                check(L_.yolo_nchw_f32_to_nhwc_bf16(ptr(g_flat), N, y.C, y.H, y.W, g.p, y.C, 1, 1, st), "gflat->nhwc")
+                g_act = g
+                li -= 1
+            elif L.kind == "pool":
+                # g_act = gradient wrt the pooled output; produce gradient wrt the conv in front
+                lc = li - 1
+                Lc = self.layers[lc]
+                assert Lc.kind == "conv" and Lc.lrelu, "MaxPool2d is expected right after conv+LeakyReLU"
+                yfull = ws["acts"][lc]
+                g = self._grad_buf(ws, lc, N, dev)
+                pd = PoolDesc(N, yfull.H, yfull.W, yfull.C, 1, 1)
+                check(L_.yolo_maxpool2_bwd_lrelu(ctypes.byref(pd), yfull.p, g_act.p, self.SLOPE, g.p, st), "maxpool_bwd")
+                g_act = g
+                li -= 1
+            elif L.kind == "conv":
+                g = g_act  # dZ of this layer, flat-geometry buffer
+                xin = input_of(li)
+                # ---- weight + bias gradient
+                db = torch.zeros_like(L.bias, dtype=torch.float32)
+                dw = torch.empty_like(L.weight, dtype=torch.float32)
+                if L.first:
+                    xcol = ws["misc"].get("xcol")
+                    if xcol is None:
+                        xcol = Act(N, L.Hout, L.Wout, 7 * 32, 1, dev)
+                        ws["misc"]["xcol"] = xcol
+                    check(L_.yolo_im2col_rows(xin.p, xin.img_stride, xin.row_stride, xin.px_stride, 2, 7, 32, N, L.Hout, L.Wout, 1, xcol.p, st), "im2col_rows")
+                    dwp = torch.zeros((L.Cout, 7, 8, 4), dtype=torch.float32, device=dev)
+                    split = max(1, min(1024, g.slots // 4096))
+                    wd = WgradDesc(g.slots, g.px_stride, xcol.px_stride, L.Cout, 7 * 32, 1, 1, 0, xcol.row_stride, split, 0)
+                    check(L_.yolo_wgrad(ctypes.byref(wd), xcol.p, g.p, ptr(dwp), ptr(db), st), "wgrad conv0")
+                    check(L_.yolo_unpack_conv_wgrad(ptr(dwp), L.Cout, 3, 7, 7, 4, 8, ptr(dw), 0, st), "unpack")
+                else:
+                    dwp = torch.zeros((L.Cout, L.K, L.K, L.Cin), dtype=torch.float32, device=dev)
+                    tiles = ((L.Cout + 127) // 128) * ((L.Cin + 127) // 128) * L.K * L.K
+                    split = max(1, min(g.slots // 256, (1024 + tiles - 1) // tiles))
+                    wd = WgradDesc(g.slots, g.px_stride, xin.px_stride, L.Cout, L.Cin, L.K, L.K, L.pad, xin.row_stride, split, 0)
+                    check(L_.yolo_wgrad(ctypes.byref(wd), xin.p, g.p, ptr(dwp), ptr(db), st), f"wgrad conv{li}")
+                    check(L_.yolo_unpack_conv_wgrad(ptr(dwp), L.Cout, L.Cin, L.K, L.K, L.Cin, L.K, ptr(dw), 0, st), "unpack")
+                grads[li] = (dw, db)
+                # ---- data gradient
+                if li == 0:
+                    gx = None
+                    if need_gx:
+                        if L.first:
+                            raise NotImplementedError("gradient wrt the input image is not provided for the 7x7 stem")
+                        gx = self._dgrad_to_input(li, g, N, dev, st)
+                    self._release(key, ws)
+                    return gx, [grads[i][j] for i in sorted(grads) for j in (0, 1)]
+                _, wdg = self._pack(li, True)
+                prev = self.layers[li - 1]
+                d = IgemmDesc()
+                d.N, d.Ho, d.Wo = N, L.Hin, L.Win            # gradient grid = this layer's input grid
+                d.in_img_stride, d.in_row_stride, d.in_px_stride = g.img_stride, g.row_stride, g.px_stride
+                d.in_off = g.interior_off(L.K - 1 - L.pad)
+                d.stride, d.KH, d.KW, d.tap_len, d.Cout = 1, L.K, L.K, L.Cout, L.Cin
+                d.slope, d.out_fp32, d.split_k = self.SLOPE, 0, 1
+                if prev.kind == "conv":
+                    gp = self._grad_buf(ws, li - 1, N, dev)
+                    d.out_img_stride, d.out_row_stride, d.out_px_stride, d.out_off = self._grad_out_strides(prev, gp)
+                    yprev = ws["acts"][li - 1]
+                    if prev.lrelu:
+                        d.epilogue = EPI_MUL_DLRELU
+                        d.aux_img_stride, d.aux_row_stride, d.aux_px_stride, d.aux_off = yprev.img_stride, yprev.row_stride, yprev.px_stride, yprev.interior_off()
+                        aux = yprev.p
+                    else:
+                        d.epilogue, aux = EPI_NONE, None
+                    check(L_.yolo_igemm(ctypes.byref(d), g.p, ptr(wdg), None, aux, gp.p, st), f"dgrad conv{li}")
+                    g_act = gp
+                elif prev.kind == "pool":
+                    gp = ws["misc"].get(("gpool", li))
+                    if gp is None:
+                        gp = Act(N, L.Hin, L.Win, L.Cin, 1, dev)
+                        ws["misc"][("gpool", li)] = gp
+                    d.out_img_stride, d.out_row_stride, d.out_px_stride, d.out_off = gp.img_stride, gp.row_stride, gp.px_stride, gp.interior_off()
+                    d.epilogue = EPI_NONE
+                    check(L_.yolo_igemm(ctypes.byref(d), g.p, ptr(wdg), None, None, gp.p, st), f"dgrad conv{li}")
+                    g_act = gp
+                else:
+                    raise AssertionError("conv after flatten/fc")
+                li -= 1
+        raise AssertionError("unreachable")
+
+    def _apply_dlrelu_into(self, graw: Act, y: Act, L: Layer, g: Act, st):
+        """g(interior, possibly zero-stuffed) = graw * lrelu'(y) -- used only at plan ends (rare path)."""
+        gi = graw.interior().float()
+        if L.lrelu:
+            gi = gi * torch.where(y.interior().float() > 0, 1.0, self.SLOPE)
+        gi = gi.to(torch.bfloat16)
+        if L.stride == 1 or L.first:
+            g.interior().copy_(gi)
+        else:
+            g.interior()[:, 0::2, 0::2, :][:, : gi.shape[1], : gi.shape[2], :].copy_(gi)
+
+    def _dgrad_to_input(self, li, g: Act, N, dev, st):
+        """data gradient of the first conv of a plan whose input is a feature map (DetectionHead)."""
+        L = self.layers[li]
+        _, wdg = self._pack(li, True)
+        gi = Act(N, L.Hin, L.Win, L.Cin, 1, dev)
+        d = IgemmDesc()
+        d.N, d.Ho, d.Wo = N, L.Hin, L.Win
+        d.in_img_stride, d.in_row_stride, d.in_px_stride = g.img_stride, g.row_stride, g.px_stride
+        d.in_off = g.interior_off(L.K - 1 - L.pad)
+        d.stride, d.KH, d.KW, d.tap_len, d.Cout = 1, L.K, L.K, L.Cout, L.Cin
+        d.out_img_stride, d.out_row_stride, d.out_px_stride, d.out_off = gi.img_stride, gi.row_stride, gi.px_stride, gi.interior_off()
+        d.epilogue, d.slope, d.out_fp32, d.split_k = EPI_NONE, self.SLOPE, 0, 1
+        check(lib().yolo_igemm(ctypes.byref(d), g.p, ptr(wdg), None, None, gi.p, st), "dgrad input")
+        gx = torch.empty((N, L.Cin, L.Hin, L.Win), dtype=torch.float32, device=dev)
+        check(lib().yolo_nhwc_bf16_to_nchw_f32(gi.p, N, L.Cin, L.Hin, L.Win, 1, ptr(gx), st), "gx nhwc->nchw")
+        return gx
+
+
+class PlanFunction(torch.autograd.Function):
+    """autograd bridge: forward/backward of a whole plan as ONE node (no per-layer autograd graph)."""
+
+    @staticmethod
+    def forward(ctx, plan: Plan, drop_training: bool, x: torch.Tensor, *params):
+        need = any(ctx.needs_input_grad)
+        out, saved = plan.forward(x, need, drop_training)
+        ctx.plan = plan
+        ctx.saved = saved
+        ctx.x_needs = x.requires_grad
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        if ctx.saved is None:
+            raise RuntimeError("backward through a plan that ran without grad")
+        gx, pg = ctx.plan.backward(ctx.saved, gout, ctx.x_needs)
+        ctx.saved = None
+        return (None, None, gx, *pg)
+
+
+def run_plan(plan: Plan, x: torch.Tensor, drop_training: bool) -> torch.Tensor:
+    _hip.require_cuda(x)
+    return PlanFunction.apply(plan, drop_training, x, *plan.params)
