@@ -51,25 +51,33 @@ def test_train_step_gradients_vs_cpu_autograd(model):
     N = 2
     x = torch.from_numpy(synth.synth_images(N, 3))
     t = torch.from_numpy(synth.synth_targets(N, 21, max_obj=4))
+    from test_gpu_layers import bf16_faithful
     ref = copy.deepcopy(model).cpu().eval()     # eval: dropout off on both sides
+    # stock torch.nn with the GPU path's storage precision (bf16 weights / stored activations)
+    ref_net = torch.nn.Sequential(bf16_faithful(ref.backbone.features), bf16_faithful(ref.head))
     crit = YOLOLoss()
-    lr, _ = crit(ref(x), t)
+    lr, _ = crit(ref_net(x.to(torch.bfloat16).float()).view(-1, 7, 7, 30), t)
     lr.backward()
     m = model.cuda().eval()
     m.zero_grad()
     lg, dg = crit(m(x.cuda()), t.cuda())
     lg.backward()
     assert abs(lg.item() - lr.item()) < 0.05 * abs(lr.item())
-    worst = 0.0
+    report, bad = [], []
     for (n1, p1), (_, p2) in zip(m.named_parameters(), ref.named_parameters()):
         assert p1.grad is not None, n1
-        g1, g2 = p1.grad.float().cpu().flatten(), p2.grad.flatten()
-        cos = torch.dot(g1, g2) / (g1.norm() * g2.norm() + 1e-30)
-        rel = (g1 - g2).norm() / (g2.norm() + 1e-30)
-        worst = max(worst, rel.item())
-        assert cos > 0.995 and rel < 0.1, (n1, cos.item(), rel.item())
+        g1, g2 = p1.grad.double().cpu().flatten(), p2.grad.double().flatten()
+        cos = (torch.dot(g1, g2) / (g1.norm() * g2.norm() + 1e-30)).item()
+        rel = ((g1 - g2).norm() / (g2.norm() + 1e-30)).item()
+        report.append(f"{n1:34s} cos {cos:.5f} rel {rel:.4f} |ref| {g2.norm().item():.3e}")
+        # end-to-end agreement is limited by LeakyReLU gates / pool arg-maxes that flip when a
+        # pre-activation ~0 is accumulated in a different order (each flip changes that unit's
+        # gradient x10); the kernels themselves are checked layer by layer below.
+        if not (cos > 0.9 and rel < 0.4):
+            bad.append(n1)
     model.cpu()
-    print("worst relative gradient error", worst)
+    print("\n".join(report))
+    assert not bad, "\n".join(report)
 
 
 def test_loss_decreases_with_adam(model):
@@ -90,3 +98,72 @@ def test_loss_decreases_with_adam(model):
         opt.step()
         losses.append(d["total"])
     assert np.isfinite(losses).all() and losses[-1] < losses[0], losses
+
+
+def test_every_layer_teacher_forced(model):
+    """Full-size kernels, one at a time: take the activations / gradients the GPU pass stored and
+    recompute every conv layer's forward, weight-, bias- and data-gradient from them with stock torch
+    on the CPU.  Tolerance = one bf16 output rounding (k=1) for forward, k=3 for gradients."""
+    import torch.nn.functional as F
+    from torch.nn.grad import conv2d_input, conv2d_weight
+    from test_gpu_layers import _bf, _close
+    from yolo import YOLOLoss
+    N = 2
+    m = model.cuda().eval()
+    plan = m.hip_plan()
+    plan.debug_keep = True
+    try:
+        m.zero_grad()
+        x = torch.from_numpy(synth.synth_images(N, 3)).cuda()
+        t = torch.from_numpy(synth.synth_targets(N, 21, max_obj=4)).cuda()
+        loss, _ = YOLOLoss()(m(x), t)
+        loss.backward()
+        torch.cuda.synchronize()
+        ws, fc_saved = plan.last
+    finally:
+        plan.debug_keep = False
+        plan.last = None
+
+    def nchw(act, stuffed=False):
+        v = act.interior().float().cpu()
+        if stuffed:
+            v = v[:, 0::2, 0::2, :]
+        return v.permute(0, 3, 1, 2).contiguous()
+
+    layers = plan.layers
+    checked = 0
+    for li, L in enumerate(layers):
+        if L.kind != "conv":
+            continue
+        a_in = ws["in"] if li == 0 else ws["acts"][li - 1]
+        xin = nchw(a_in)[:, : L.Cin]
+        w = _bf(L.weight.detach().float().cpu())
+        b = L.bias.detach().float().cpu()
+        y_ref = F.leaky_relu(F.conv2d(xin, w, b, stride=L.stride, padding=L.pad), 0.1)
+        _close(nchw(ws["acts"][li]), _bf(y_ref), 1.0, f"layer {li} forward")
+        g = ws["grads"][li]
+        dz = nchw(g, stuffed=(L.stride == 2 and not L.first))[:, :, : L.Hout, : L.Wout]
+        gw_ref = conv2d_weight(xin, w.shape, dz, stride=L.stride, padding=L.pad)
+        _close(L.weight.grad, gw_ref, 3.0, f"layer {li} weight grad")
+        _close(L.bias.grad, dz.sum((0, 2, 3)), 3.0, f"layer {li} bias grad")
+        if li > 0:
+            dx_ref = conv2d_input(xin.shape, w, dz, stride=L.stride, padding=L.pad)
+            prev = layers[li - 1]
+            if prev.kind == "conv":
+                yprev = nchw(ws["acts"][li - 1])
+                dx_ref = dx_ref * torch.where(yprev > 0, 1.0, 0.1)
+                got = nchw(ws["grads"][li - 1], stuffed=(prev.stride == 2 and not prev.first))[:, :, : prev.Hout, : prev.Wout]
+            else:
+                got = nchw(ws["misc"][("gpool", li)])
+            _close(got, _bf(dx_ref), 3.0, f"layer {li} data grad")
+        checked += 1
+    assert checked == 24
+    # pools: gradient routing recomputed from the stored full-resolution activation
+    for li, L in enumerate(layers):
+        if L.kind != "pool":
+            continue
+        yfull = nchw(ws["acts"][li - 1]).requires_grad_(True)
+        F.max_pool2d(F.leaky_relu(yfull, 1.0), 2, 2).backward(nchw(ws["misc"][("gpool", li + 1)]))
+        ref = yfull.grad * torch.where(yfull.detach() > 0, 1.0, 0.1)
+        _close(nchw(ws["grads"][li - 1]), _bf(ref), 1.0, f"pool {li} backward")
+    model.cpu()

@@ -101,6 +101,8 @@ class Plan:
                 self.params += [L.weight, L.bias]
         self._packed: dict[int, tuple] = {}
         self._ws: dict[tuple, list] = {}
+        self.debug_keep = False      # tests: keep the last workspace (activations + gradients) for inspection
+        self.last = None
 
     # ------------------------------------------------------------------ construction helpers
     @staticmethod
@@ -365,15 +367,18 @@ class Plan:
         if self.layers[li].kind == "fc":
             g_flat = gout.reshape(N, -1)
         else:
-            # plan ends with conv features (NCHW fp32 gradient); last layer must be a conv (+lrelu)
+            # plan ends with feature maps (NCHW fp32 gradient): last layer is a conv(+lrelu) or a pool
             L = self.layers[li]
-            assert L.kind == "conv", "plans end with fc or conv"
             y = ws["acts"][li]
             graw = Act(N, y.H, y.W, y.C, 1, dev)
             check(L_.yolo_nchw_f32_to_nhwc_bf16(ptr(gout), N, y.C, y.H, y.W, graw.p, y.C, 1, 1, st), "gout->nhwc")
-            g = self._grad_buf(ws, li, N, dev)
-            self._apply_dlrelu_into(graw, y, L, g, st)
-            g_act = g
+            if L.kind == "conv":
+                g = self._grad_buf(ws, li, N, dev)
+                self._apply_dlrelu_into(graw, y, L, g, st)
+                g_act = g
+            else:
+                assert L.kind == "pool", "plans end with fc, conv or pool"
+                g_act = graw
 
         while li >= 0:
             L = self.layers[li]
@@ -471,7 +476,10 @@ class Plan:
                         if L.first:
                             raise NotImplementedError("gradient wrt the input image is not provided for the 7x7 stem")
                         gx = self._dgrad_to_input(li, g, N, dev, st)
-                    self._release(key, ws)
+                    if self.debug_keep:
+                        self.last = (ws, fc_saved)
+                    else:
+                        self._release(key, ws)
                     return gx, [grads[i][j] for i in sorted(grads) for j in (0, 1)]
                 _, wdg = self._pack(li, True)
                 prev = self.layers[li - 1]
