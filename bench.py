@@ -1,0 +1,228 @@
+#!/usr/bin/env python3
+"""Benchmark of the YOLOv1 hot path on MI355X.  Prints ONE JSON line (rank 0).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch 64] [--no-train] [--no-cpu]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+metric / value : images/sec of the forward pass of YOLOv1 (24-conv backbone + FC head) on synthetic
+                 448x448 batches of `--batch` (64) images per GPU, inputs resident in HBM, bf16 storage /
+                 fp32 MFMA accumulation -- BASELINE.json configs[1].  A "step" = one forward over one batch.
+extra keys     : "train" = forward + YOLOLoss + backward + clip + Adam step (configs[2]; with N > 1 the
+                 gradients are all-reduced over RCCL: configs[3]);  "nms" = decode + per-image NMS boxes/sec
+                 (configs[4]'s post-processing);  "roofline" for the dominant kernel (implicit-GEMM MFMA
+                 kernel, forward launches);  "cpu_baseline" = the stock-torch CPU restatement of the
+                 reference network (oracle/torch_ref.py) timed on this box's host cores.
+Multi-GPU: one process per GPU, batches shard (weak scaling), forward has no collective.
+"""
+
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "yolo-v1_amd"), os.path.join(ROOT, "tests", "golden")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+MFMA_BF16_PEAK_TFLOPS = 2500.0   # dense bf16, /opt/skills/guides/MI355X_MICROARCH.md
+HBM_PEAK_GBS = 8000.0
+
+
+def _sync_all(world):
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+
+
+def timed_steps(fn, steps, warmup, world):
+    """W untimed + K timed steps bracketed by barrier + synchronize on both sides; max over ranks."""
+    for _ in range(warmup):
+        fn()
+    _sync_all(world)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    _sync_all(world)
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    return dt
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=64, help="images per GPU")
+    ap.add_argument("--no-train", action="store_true")
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-nms", action="store_true")
+    ap.add_argument("--layers", action="store_true", help="print the per-layer kernel table to stderr")
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != a.gpus and world > 1:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    import synth
+    from yolo import YOLOLoss, YOLOv1, engine, ops
+    from yolo.parallel import GradAllReduce
+
+    B = a.batch
+    torch.manual_seed(0)
+    model = YOLOv1().to(dev)
+    if world > 1:
+        for p_ in model.parameters():
+            dist.broadcast(p_.data, 0)
+    # synthetic inputs, resident in HBM before any timed region
+    rng = np.random.Generator(np.random.PCG64([0, 5 + rank]))
+    x = torch.from_numpy(rng.standard_normal((B, 3, 448, 448), dtype=np.float32)).to(dev)
+    tgt = torch.from_numpy(synth.synth_targets(B, 1 + rank)).to(dev)
+
+    # ---------------------------------------------------------------- forward (the headline value)
+    model.eval()
+
+    def fwd():
+        with torch.no_grad():
+            return model(x)
+
+    dt_f = timed_steps(fwd, a.steps, a.warmup, world)
+    fwd_ips = world * B * a.steps / dt_f
+
+    # ---------------------------------------------------------------- roofline of the dominant kernel
+    roof = None
+    layer_rows = []
+    if rank == 0:
+        engine.TIMERS = []
+        reps = 3
+        for _ in range(reps):
+            fwd()
+        torch.cuda.synchronize()
+        agg = {}
+        for tag, kern, flops, e0, e1 in engine.TIMERS:
+            d = agg.setdefault(tag, [kern, flops, 0.0])
+            d[2] += e0.elapsed_time(e1) / reps
+        engine.TIMERS = None
+        ig_ms = sum(v[2] for v in agg.values() if v[0] == "igemm")
+        ig_fl = sum(v[1] for v in agg.values() if v[0] == "igemm")
+        n_launch = sum(1 for v in agg.values() if v[0] == "igemm")
+        layer_rows = [(k, v[0], v[1], v[2]) for k, v in agg.items()]
+        ach = ig_fl / (ig_ms * 1e-3) / 1e12
+        roof = {"kernel": "igemm_kernel (implicit-GEMM conv/FC, v_mfma_f32_32x32x16_bf16)", "bound": "mfma",
+                "achieved": round(ach, 2), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4),
+                "traffic": None, "launches_per_step": n_launch, "avg_launch_ms": round(ig_ms / n_launch, 4),
+                "flops_per_step": ig_fl, "kernel_ms_per_step": round(ig_ms, 3)}
+        if a.layers:
+            for k, kern, fl, ms in layer_rows:
+                print(f"{k:14s} {kern:14s} {ms:8.3f} ms {fl / max(ms, 1e-9) / 1e9:9.1f} TFLOP/s", file=sys.stderr)
+
+    # ---------------------------------------------------------------- train step
+    train = None
+    if not a.no_train:
+        model.train()
+        crit = YOLOLoss()
+        opt = torch.optim.Adam(model.parameters(), lr=1e-4, weight_decay=5e-4)
+        ar = GradAllReduce(model.parameters()) if world > 1 else None
+
+        def step():
+            opt.zero_grad(set_to_none=True)
+            loss, _ = crit(model(x), tgt)
+            loss.backward()
+            if ar is not None:
+                ar.all_reduce_mean()
+            torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm=10.0)
+            opt.step()
+
+        ksteps = max(3, a.steps // 2)
+        dt_t = timed_steps(step, ksteps, max(2, a.warmup // 2), world)
+        train = {"value": round(world * B * ksteps / dt_t, 1), "unit": "images/s", "ms_per_step": round(1e3 * dt_t / ksteps, 3),
+                 "steps": ksteps, "global_batch": world * B,
+                 "includes": "zero_grad, forward, YOLOLoss fwd+bwd (HIP), backward (HIP), " + ("RCCL grad all-reduce, " if world > 1 else "") + "clip_grad_norm_(10), Adam(lr 1e-4, wd 5e-4)",
+                 "flops_per_image": 120.8e9, "first_layer_dgrad": "skipped (input needs no gradient)"}
+        model.eval()
+
+    # ---------------------------------------------------------------- decode + NMS
+    nms = None
+    if not a.no_nms and rank == 0:
+        p01 = torch.from_numpy(np.random.Generator(np.random.PCG64([0, 99])).uniform(0, 1, size=(64, 7, 7, 30)).astype(np.float32)).to(dev)
+
+        def post():
+            rec, cnt = ops.decode(p01, 0.3, 7, 2, 20)
+            return ops.nms(rec, cnt, 0.4, 1)
+
+        for _ in range(5):
+            post()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(200):
+            post()
+        torch.cuda.synchronize()
+        dtp = (time.perf_counter() - t0) / 200
+        nms = {"value": round(64 * 98 / dtp, 1), "unit": "raw boxes/s", "us_per_batch64": round(dtp * 1e6, 1), "config": "64x(7,7,30)~U(0,1), conf 0.3, nms 0.4, metrics variant"}
+
+    # ---------------------------------------------------------------- CPU baseline (rank 0, N=1 only)
+    cpu = None
+    if rank == 0 and world == 1 and not a.no_cpu:
+        from oracle import oracle as O
+        from oracle.torch_ref import RefYOLOv1
+        ref = RefYOLOv1().eval()
+        cores = torch.get_num_threads()
+        xs = x[:8].cpu()
+        with torch.no_grad():
+            ref(xs[:1])
+            t0 = time.perf_counter()
+            n_img = 0
+            while time.perf_counter() - t0 < 12.0:
+                ref(xs)
+                n_img += 8
+            dtc = time.perf_counter() - t0
+        cpu = {"value": round(n_img / dtc, 2), "unit": "images/s", "cores": cores, "kind": "port",
+               "sample": f"forward of oracle/torch_ref.RefYOLOv1 (stock torch.nn fp32, the reference's layer table) on batches of 8, {n_img} images in {dtc:.1f} s"}
+        if nms is not None:
+            pn = p01.cpu().numpy()
+            t0 = time.perf_counter()
+            reps = 0
+            while time.perf_counter() - t0 < 3.0:
+                for n in range(64):
+                    O.nms(O.decode(pn[n], 0.3), 0.4, 1)
+                reps += 1
+            nms["cpu_baseline"] = {"value": round(reps * 64 * 98 / (time.perf_counter() - t0), 1), "unit": "raw boxes/s", "cores": 1, "kind": "port",
+                                   "sample": f"oracle/yolo_oracle.c decode+nms, {reps} x 64 images"}
+
+    if rank == 0:
+        out = {
+            "metric": "images/sec at 448x448, forward (YOLOv1Backbone + FC head)", "value": round(fwd_ips, 1), "unit": "images/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * dt_f / a.steps, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "BASELINE.json configs[1]: batch=64/GPU 448x448 forward-only, YOLOv1Backbone + FC head, 1xMI355X per rank",
+                       "global_batch": world * B, "per_gpu_batch": B, "weights": "random init (torch default, seed 0)",
+                       "flops_per_image": 40.57e9, "parallelism": f"dp{world}" if world > 1 else "single"},
+            "roofline": roof, "cpu_baseline": cpu, "train": train, "nms": nms,
+        }
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

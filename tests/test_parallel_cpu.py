@@ -1,0 +1,82 @@
+"""CPU, world_size 2 over gloo: the data-parallel gradient path (yolo.parallel) reproduces the
+single-process gradients of the global batch ('N-way split == full batch')."""
+
+import os
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _tiny_model():
+    import torch.nn as nn
+    torch.manual_seed(0)
+    return nn.Sequential(nn.Conv2d(3, 8, 3, 1, 1), nn.LeakyReLU(0.1), nn.Flatten(), nn.Linear(8 * 14 * 14, 7 * 7 * 30))
+
+
+def _worker(rank, world, port, q):
+    for p in (ROOT, os.path.join(ROOT, "yolo-v1_amd"), os.path.join(ROOT, "tests", "golden")):
+        sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import synth
+    from yolo import YOLOLoss
+    from yolo.parallel import GradAllReduce, broadcast_parameters, shard_batch
+    torch.manual_seed(100 + rank)          # different init per rank: broadcast must fix it
+    model = _tiny_model()
+    if rank != 0:
+        with torch.no_grad():
+            for p in model.parameters():
+                p.add_(1.0)
+    broadcast_parameters(model)
+    N = 8
+    x = torch.from_numpy(synth.synth_normal((N, 3, 14, 14), 7))
+    t = torch.from_numpy(synth.synth_targets(N, 3))
+    sl = shard_batch(N, rank, world)
+    loss, _ = YOLOLoss()(model(x[sl]).view(-1, 7, 7, 30), t[sl])
+    loss.backward()
+    GradAllReduce(model.parameters(), big_bytes=1 << 12).all_reduce_mean()   # exercises both the big and the packed path
+    q.put((rank, [p.grad.numpy().copy() for p in model.parameters()], [p.detach().numpy().copy() for p in model.parameters()]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gradients_equal_full_batch():
+    sys.path.insert(0, os.path.join(ROOT, "yolo-v1_amd"))
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import synth
+    from yolo import YOLOLoss
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in procs], key=lambda r: r[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    # single-process reference on the global batch with rank 0's parameters
+    model = _tiny_model()
+    x = torch.from_numpy(synth.synth_normal((8, 3, 14, 14), 7))
+    t = torch.from_numpy(synth.synth_targets(8, 3))
+    loss, _ = YOLOLoss()(model(x).view(-1, 7, 7, 30), t)
+    loss.backward()
+    for r in res:
+        for g, p_now, p_ref in zip(r[1], r[2], model.parameters()):
+            assert torch.equal(torch.from_numpy(p_now), p_ref.detach())                       # broadcast worked
+            torch.testing.assert_close(torch.from_numpy(g), p_ref.grad, rtol=1e-5, atol=1e-6)  # averaged shards == global batch
+    for a, b in zip(res[0][1], res[1][1]):
+        assert (a == b).all()                                               # ranks agree bit for bit
+
+
+def test_shard_batch():
+    from yolo.parallel import shard_batch
+    assert [shard_batch(512, r, 8) for r in (0, 7)] == [slice(0, 64), slice(448, 512)]
+    with pytest.raises(ValueError):
+        shard_batch(10, 0, 4)

@@ -31,6 +31,29 @@ def _round_up(a: int, b: int) -> int:
     return (a + b - 1) // b * b
 
 
+# bench.py / profiling: when TIMERS is a list, every MFMA / pool launch is bracketed by events on the
+# launch stream and (tag, kernel, flops, e0, e1) is appended.  None (default) = no events at all.
+TIMERS: list | None = None
+
+
+class _timed:
+    def __init__(self, tag: str, kernel: str, flops: float = 0.0):
+        self.tag, self.kernel, self.flops = tag, kernel, flops
+
+    def __enter__(self):
+        if TIMERS is not None:
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+        return self
+
+    def __exit__(self, *exc):
+        if TIMERS is not None:
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record()
+            TIMERS.append((self.tag, self.kernel, self.flops, self.e0, e1))
+        return False
+
+
 class Act:
     """Zero-haloed NHWC bf16 activation: [N][H+2h][W+2h][C] plus guard bands of zeros."""
 
@@ -266,11 +289,13 @@ class Plan:
                 wf, _ = self._pack(li, train)
                 d = self._conv_desc(L, cur, nxt)
                 b = L.bias.detach()
-                check(L_.yolo_igemm(ctypes.byref(d), cur.p, ptr(wf), ptr(b), None, nxt.p, st), f"igemm conv{li}")
+                with _timed(f"conv{li}", "igemm", 2.0 * N * L.Hout * L.Wout * L.Cout * L.Cin * L.K * L.K):
+                    check(L_.yolo_igemm(ctypes.byref(d), cur.p, ptr(wf), ptr(b), None, nxt.p, st), f"igemm conv{li}")
                 cur = nxt
             elif L.kind == "pool":
                 pd = PoolDesc(N, cur.H, cur.W, cur.C, cur.halo, nxt.halo)
-                check(L_.yolo_maxpool2_fwd(ctypes.byref(pd), cur.p, nxt.p, st), "maxpool")
+                with _timed(f"pool{li}", "maxpool2_fwd"):
+                    check(L_.yolo_maxpool2_fwd(ctypes.byref(pd), cur.p, nxt.p, st), "maxpool")
                 cur = nxt
             elif L.kind == "flatten":
                 check(L_.yolo_nhwc_bf16_to_nchw_bf16(cur.p, N, cur.C, cur.H, cur.W, cur.halo, ptr(nxt), st), "flatten")
@@ -293,14 +318,16 @@ class Plan:
                 if splits > 1:
                     acc = torch.zeros((N, L.Cout), dtype=torch.float32, device=dev)
                     d.epilogue, d.split_k = EPI_NONE, splits
-                    check(L_.yolo_igemm(ctypes.byref(d), ptr(xin), ptr(wf), None, None, ptr(acc), st), f"igemm fc{li}")
+                    with _timed(f"fc{li}", "igemm", 2.0 * N * L.Cout * L.Cin):
+                        check(L_.yolo_igemm(ctypes.byref(d), ptr(xin), ptr(wf), None, None, ptr(acc), st), f"igemm fc{li}")
                     yb = torch.empty((N, L.Cout), dtype=torch.bfloat16, device=dev) if not last else None
                     yf = torch.empty((N, L.Cout), dtype=torch.float32, device=dev) if last else None
                     check(L_.yolo_bias_lrelu_rows(ptr(acc), ptr(b), N, L.Cout, self.SLOPE if L.lrelu else 1.0, ptr(yb), ptr(yf), st), "bias_lrelu_rows")
                 else:
                     yf = torch.empty((N, L.Cout), dtype=torch.float32, device=dev)
                     d.epilogue, d.split_k = (EPI_BIAS_LRELU if L.lrelu else EPI_BIAS), 1
-                    check(L_.yolo_igemm(ctypes.byref(d), ptr(xin), ptr(wf), ptr(b), None, ptr(yf), st), f"igemm fc{li}")
+                    with _timed(f"fc{li}", "igemm", 2.0 * N * L.Cout * L.Cin):
+                        check(L_.yolo_igemm(ctypes.byref(d), ptr(xin), ptr(wf), ptr(b), None, ptr(yf), st), f"igemm fc{li}")
                     yb = None
                     if not last:
                         yb = torch.empty((N, L.Cout), dtype=torch.bfloat16, device=dev)
@@ -394,7 +421,8 @@ class Plan:
                 dw = torch.empty_like(L.weight, dtype=torch.float32)
                 db = torch.zeros_like(L.bias, dtype=torch.float32)
                 wd = WgradDesc(N, ldg, L.Cin, L.Cout, L.Cin, 1, 1, 0, 0, 1, 0)
-                check(L_.yolo_wgrad(ctypes.byref(wd), ptr(xin), ptr(gb), ptr(dw), ptr(db), st), f"wgrad fc{li}")
+                with _timed(f"fc{li}.wgrad", "wgrad", 2.0 * N * L.Cout * L.Cin):
+                    check(L_.yolo_wgrad(ctypes.byref(wd), ptr(xin), ptr(gb), ptr(dw), ptr(db), st), f"wgrad fc{li}")
                 grads[li] = (dw, db)
                 # data gradient -> fp32 (N, K)
                 need_prev = li > 0 or need_gx
@@ -413,7 +441,8 @@ class Plan:
                         d.aux_img_stride, d.aux_row_stride, d.aux_px_stride, d.aux_off = L.Cin, 0, L.Cin, 0
                         aux = ptr(xin)
                     gprev = torch.empty((N, L.Cin), dtype=torch.float32, device=dev)
-                    check(L_.yolo_igemm(ctypes.byref(d), ptr(gb), ptr(wt), None, aux, ptr(gprev), st), f"dgrad fc{li}")
+                    with _timed(f"fc{li}.dgrad", "igemm", 2.0 * N * L.Cout * L.Cin):
+                        check(L_.yolo_igemm(ctypes.byref(d), ptr(gb), ptr(wt), None, aux, ptr(gprev), st), f"dgrad fc{li}")
                     g_flat = gprev
                 li -= 1
             elif L.kind == "flatten":
@@ -441,7 +470,8 @@ class Plan:
                 yfull = ws["acts"][lc]
                 g = self._grad_buf(ws, lc, N, dev)
                 pd = PoolDesc(N, yfull.H, yfull.W, yfull.C, 1, 1)
-                check(L_.yolo_maxpool2_bwd_lrelu(ctypes.byref(pd), yfull.p, g_act.p, self.SLOPE, g.p, st), "maxpool_bwd")
+                with _timed(f"pool{li}.bwd", "maxpool2_bwd"):
+                    check(L_.yolo_maxpool2_bwd_lrelu(ctypes.byref(pd), yfull.p, g_act.p, self.SLOPE, g.p, st), "maxpool_bwd")
                 g_act = g
                 li -= 1
             elif L.kind == "conv":
@@ -459,14 +489,16 @@ class Plan:
                     dwp = torch.zeros((L.Cout, 7, 8, 4), dtype=torch.float32, device=dev)
                     split = max(1, min(1024, g.slots // 4096))
                     wd = WgradDesc(g.slots, g.px_stride, xcol.px_stride, L.Cout, 7 * 32, 1, 1, 0, xcol.row_stride, split, 0)
-                    check(L_.yolo_wgrad(ctypes.byref(wd), xcol.p, g.p, ptr(dwp), ptr(db), st), "wgrad conv0")
+                    with _timed(f"conv{li}.wgrad", "wgrad", 2.0 * N * L.Hout * L.Wout * L.Cout * 147):
+                        check(L_.yolo_wgrad(ctypes.byref(wd), xcol.p, g.p, ptr(dwp), ptr(db), st), "wgrad conv0")
                     check(L_.yolo_unpack_conv_wgrad(ptr(dwp), L.Cout, 3, 7, 7, 4, 8, ptr(dw), 0, st), "unpack")
                 else:
                     dwp = torch.zeros((L.Cout, L.K, L.K, L.Cin), dtype=torch.float32, device=dev)
                     tiles = ((L.Cout + 127) // 128) * ((L.Cin + 127) // 128) * L.K * L.K
                     split = max(1, min(g.slots // 256, (1024 + tiles - 1) // tiles))
                     wd = WgradDesc(g.slots, g.px_stride, xin.px_stride, L.Cout, L.Cin, L.K, L.K, L.pad, xin.row_stride, split, 0)
-                    check(L_.yolo_wgrad(ctypes.byref(wd), xin.p, g.p, ptr(dwp), ptr(db), st), f"wgrad conv{li}")
+                    with _timed(f"conv{li}.wgrad", "wgrad", 2.0 * N * L.Hout * L.Wout * L.Cout * L.Cin * L.K * L.K):
+                        check(L_.yolo_wgrad(ctypes.byref(wd), xin.p, g.p, ptr(dwp), ptr(db), st), f"wgrad conv{li}")
                     check(L_.yolo_unpack_conv_wgrad(ptr(dwp), L.Cout, L.Cin, L.K, L.K, L.Cin, L.K, ptr(dw), 0, st), "unpack")
                 grads[li] = (dw, db)
                 # ---- data gradient
@@ -499,7 +531,8 @@ class Plan:
                         aux = yprev.p
                     else:
                         d.epilogue, aux = EPI_NONE, None
-                    check(L_.yolo_igemm(ctypes.byref(d), g.p, ptr(wdg), None, aux, gp.p, st), f"dgrad conv{li}")
+                    with _timed(f"conv{li}.dgrad", "igemm", 2.0 * N * L.Hout * L.Wout * L.Cout * L.Cin * L.K * L.K):
+                        check(L_.yolo_igemm(ctypes.byref(d), g.p, ptr(wdg), None, aux, gp.p, st), f"dgrad conv{li}")
                     g_act = gp
                 elif prev.kind == "pool":
                     gp = ws["misc"].get(("gpool", li))
@@ -508,7 +541,8 @@ class Plan:
                         ws["misc"][("gpool", li)] = gp
                     d.out_img_stride, d.out_row_stride, d.out_px_stride, d.out_off = gp.img_stride, gp.row_stride, gp.px_stride, gp.interior_off()
                     d.epilogue = EPI_NONE
-                    check(L_.yolo_igemm(ctypes.byref(d), g.p, ptr(wdg), None, None, gp.p, st), f"dgrad conv{li}")
+                    with _timed(f"conv{li}.dgrad", "igemm", 2.0 * N * L.Hout * L.Wout * L.Cout * L.Cin * L.K * L.K):
+                        check(L_.yolo_igemm(ctypes.byref(d), g.p, ptr(wdg), None, None, gp.p, st), f"dgrad conv{li}")
                     g_act = gp
                 else:
                     raise AssertionError("conv after flatten/fc")
