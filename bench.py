@@ -141,7 +141,8 @@ def main():
     if not a.no_train:
         model.train()
         crit = YOLOLoss()
-        opt = torch.optim.Adam(model.parameters(), lr=1e-4, weight_decay=5e-4)
+        from yolo.optim import Adam
+        opt = Adam(model.parameters(), lr=1e-4, weight_decay=5e-4, max_grad_norm=10.0)  # clip_grad_norm_(10) + Adam fused
         ar = GradAllReduce(model.parameters()) if world > 1 else None
 
         def step():
@@ -150,11 +151,18 @@ def main():
             loss.backward()
             if ar is not None:
                 ar.all_reduce_mean()
-            torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm=10.0)
             opt.step()
 
         ksteps = max(3, a.steps // 2)
         dt_t = timed_steps(step, ksteps, max(2, a.warmup // 2), world)
+        if a.layers and rank == 0:
+            engine.TIMERS = []
+            step()
+            torch.cuda.synchronize()
+            for tag, kern, flops, e0, e1 in engine.TIMERS:
+                ms = e0.elapsed_time(e1)
+                print(f"train {tag:16s} {kern:14s} {ms:8.3f} ms {flops / max(ms, 1e-9) / 1e9:9.1f} TFLOP/s", file=sys.stderr)
+            engine.TIMERS = None
         train = {"value": round(world * B * ksteps / dt_t, 1), "unit": "images/s", "ms_per_step": round(1e3 * dt_t / ksteps, 3),
                  "steps": ksteps, "global_batch": world * B,
                  "includes": "zero_grad, forward, YOLOLoss fwd+bwd (HIP), backward (HIP), " + ("RCCL grad all-reduce, " if world > 1 else "") + "clip_grad_norm_(10), Adam(lr 1e-4, wd 5e-4)",

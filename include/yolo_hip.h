@@ -62,7 +62,8 @@ int yolo_decode_gt(const float *tgt, int N, int S, int B, int C,
 #define YOLO_NMS_METRICS 1   /* metrics.py:258-341: union==0 -> 0, no eps, output grouped by class         */
 
 /* Replaces YOLOInference.non_max_suppression (src/yolo/inference.py:298-317, variant 0) and
- * mAPMetric._apply_nms (src/yolo/metrics.py:270-296, variant 1), one wavefront per image (two boxes per lane).
+ * mAPMetric._apply_nms (src/yolo/metrics.py:270-296, variant 1), one 4-wave workgroup per image (ballot-built
+ * suppression matrix, bit-mask greedy sweep).
  *   rec [N][max_per_img][6] f64 as written by yolo_decode; counts [N]
  *   keep [N][max_per_img] int32: indices into the image's records in the reference's OUTPUT order;
  *   keep_counts [N].
@@ -221,6 +222,22 @@ int yolo_scale_rows_to_bf16(const float *x, const unsigned char *mask, float sca
                             int R, int Cc, int ld, void *y_bf16, yolo_stream_t stream);
 /* nn.Dropout forward on bf16: y = mask ? x * scale : 0 (mask u8 drawn by the caller's RNG). */
 int yolo_dropout_bf16(const void *x_bf16, const unsigned char *mask, float scale, long n, void *y_bf16, yolo_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Optimizer step (HBM-bound).  Replaces clip_grad_norm_(max_norm=10) + optim.Adam(lr, weight_decay)
+ * of the reference's train step (src/yolo/training/trainer.py:79-95, src/train.py:177-179).
+ * ------------------------------------------------------------------------------------------- */
+/* *acc += sum(g[i]^2)  (device double, caller zero-fills once per step; one call per tensor). */
+int yolo_sumsq_f32(const float *g, long n, double *acc, yolo_stream_t stream);
+/* One tensor of torch.optim.Adam (amsgrad=False, L2 weight decay) in a single pass; `step` is the
+ * 1-based step count.  If norm_sq != NULL the gradient is first scaled by
+ * min(1, max_norm / (sqrt(*norm_sq) + 1e-6)) exactly as clip_grad_norm_ would have.  If p_bf16 != NULL
+ * the updated parameter is also written as bf16 (same layout). */
+int yolo_adam_step(float *p, const float *g, float *exp_avg, float *exp_avg_sq, long n, float lr, float beta1,
+                   float beta2, float eps, float weight_decay, long step, const double *norm_sq,
+                   float max_norm, void *p_bf16, yolo_stream_t stream);
+/* g *= min(1, max_norm / (sqrt(*norm_sq) + 1e-6))  (stand-alone clip_grad_norm_ for other optimizers). */
+int yolo_clip_scale_f32(float *g, long n, const double *norm_sq, float max_norm, yolo_stream_t stream);
 
 #ifdef __cplusplus
 }

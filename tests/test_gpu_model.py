@@ -167,3 +167,35 @@ def test_every_layer_teacher_forced(model):
         ref = yfull.grad * torch.where(yfull.detach() > 0, 1.0, 0.1)
         _close(nchw(ws["grads"][li - 1]), _bf(ref), 1.0, f"pool {li} backward")
     model.cpu()
+
+
+def test_hip_adam_matches_torch_adam():
+    """yolo.optim.Adam(max_grad_norm=10) == clip_grad_norm_(10) + torch.optim.Adam, three steps."""
+    from yolo.optim import Adam, clip_grad_norm_
+    torch.manual_seed(0)
+    shapes = [(1000, 37), (4096,), (3, 3, 3, 5), (1 << 20,)]
+    pa = [torch.randn(s, device="cuda").requires_grad_(True) for s in shapes]
+    pb = [p.detach().clone().requires_grad_(True) for p in pa]
+    oa = Adam(pa, lr=1e-3, weight_decay=5e-4, max_grad_norm=10.0)
+    ob = torch.optim.Adam(pb, lr=1e-3, weight_decay=5e-4)
+    for it in range(3):
+        for p, q in zip(pa, pb):
+            g = torch.randn_like(p) * (3.0 if it == 1 else 0.001)   # step 1 clips, steps 0 and 2 do not
+            p.grad = g.clone()
+            q.grad = g.clone()
+        torch.nn.utils.clip_grad_norm_(pb, max_norm=10.0)
+        ob.step()
+        oa.step()
+        for p, q in zip(pa, pb):
+            torch.testing.assert_close(p, q, rtol=2e-5, atol=2e-6)
+    # stand-alone clip
+    for p, q in zip(pa, pb):
+        g = torch.randn_like(p) * 2
+        p.grad, q.grad = g.clone(), g.clone()
+    n1 = clip_grad_norm_(pa, 10.0)
+    n2 = torch.nn.utils.clip_grad_norm_(pb, 10.0)
+    torch.testing.assert_close(n1.cpu(), n2.cpu(), rtol=1e-5, atol=1e-5)
+    for p, q in zip(pa, pb):
+        torch.testing.assert_close(p.grad, q.grad, rtol=1e-5, atol=1e-7)
+    # state_dict is interchangeable with torch.optim.Adam
+    ob.load_state_dict(oa.state_dict())

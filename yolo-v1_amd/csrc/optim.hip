@@ -1,0 +1,134 @@
+// Fused optimizer step for gfx950 (HBM-bound, one pass over the 271.7 M fp32 parameters):
+// global-gradient-norm clipping + Adam with L2 weight decay, i.e. what the reference's train step
+// does with torch.nn.utils.clip_grad_norm_(max_norm=10) followed by optim.Adam(lr, weight_decay)
+// (src/yolo/training/trainer.py:79-95, src/train.py:177-179) in ~10 separate multi-tensor passes.
+//   yolo_sumsq_f32 : accumulates sum(g^2) of one tensor into a device double (fp64 atomics)
+//   yolo_adam_step : g' = g * clip + wd * p ; m,v update ; p -= lr/bc1 * m / (sqrt(v)/sqrt(bc2) + eps)
+//                    clip = min(1, max_norm / (sqrt(norm_sq) + 1e-6)) is read from device memory, so the
+//                    whole step needs no host synchronisation.  Optionally also writes bf16(p) (the
+//                    forward operand of Linear layers has the master's layout).
+// 16 B per lane on every stream (float4), grid-stride, <= 2048 workgroups.
+#include "common.h"
+
+namespace yolo {
+
+__global__ void __launch_bounds__(256) sumsq_kernel(const float *__restrict__ g, long n, double *__restrict__ acc)
+{
+    const long stride = (long)gridDim.x * blockDim.x * 4;
+    double s = 0.0;
+    for (long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += stride) {
+        if (i + 4 <= n) {
+            const float4 v = *reinterpret_cast<const float4 *>(g + i);
+            s += (double)(v.x * v.x + v.y * v.y) + (double)(v.z * v.z + v.w * v.w);
+        } else {
+            for (long k = i; k < n; ++k) s += (double)(g[k] * g[k]);
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    __shared__ double part[4];
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(acc, part[0] + part[1] + part[2] + part[3]);
+}
+
+__device__ __forceinline__ void adam1(float &p, float g, float &m, float &v, float clip, float wd, float b1, float b2, float step_size, float inv_bc2_sqrt, float eps)
+{
+    g = g * clip;
+    g = g + wd * p;                       // grad.add(param, alpha=weight_decay)
+    m = m + (g - m) * (1.0f - b1);        // exp_avg.lerp_(grad, 1 - beta1)
+    v = v * b2 + (1.0f - b2) * g * g;     // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value=1-beta2)
+    const float denom = sqrtf(v) * inv_bc2_sqrt + eps;
+    p = p - step_size * (m / denom);      // param.addcdiv_(exp_avg, denom, value=-step_size)
+}
+
+__global__ void __launch_bounds__(256) adam_kernel(float *__restrict__ p, const float *__restrict__ g, float *__restrict__ m, float *__restrict__ v, long n,
+                                                   float b1, float b2, float eps, float wd, float step_size, float inv_bc2_sqrt,
+                                                   const double *__restrict__ norm_sq, float max_norm, bf16_t *__restrict__ pb)
+{
+    float clip = 1.0f;
+    if (norm_sq) {
+        const float total = (float)sqrt(*norm_sq);
+        const float c = max_norm / (total + 1e-6f);
+        clip = c < 1.0f ? c : 1.0f;
+    }
+    const long stride = (long)gridDim.x * blockDim.x * 4;
+    for (long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += stride) {
+        if (i + 4 <= n) {
+            float4 pv = *reinterpret_cast<float4 *>(p + i);
+            const float4 gv = *reinterpret_cast<const float4 *>(g + i);
+            float4 mv = *reinterpret_cast<float4 *>(m + i), vv = *reinterpret_cast<float4 *>(v + i);
+            adam1(pv.x, gv.x, mv.x, vv.x, clip, wd, b1, b2, step_size, inv_bc2_sqrt, eps);
+            adam1(pv.y, gv.y, mv.y, vv.y, clip, wd, b1, b2, step_size, inv_bc2_sqrt, eps);
+            adam1(pv.z, gv.z, mv.z, vv.z, clip, wd, b1, b2, step_size, inv_bc2_sqrt, eps);
+            adam1(pv.w, gv.w, mv.w, vv.w, clip, wd, b1, b2, step_size, inv_bc2_sqrt, eps);
+            *reinterpret_cast<float4 *>(p + i) = pv;
+            *reinterpret_cast<float4 *>(m + i) = mv;
+            *reinterpret_cast<float4 *>(v + i) = vv;
+            if (pb) {
+                uint2 o;
+                o.x = (unsigned)f32_to_bf16(pv.x) | ((unsigned)f32_to_bf16(pv.y) << 16);
+                o.y = (unsigned)f32_to_bf16(pv.z) | ((unsigned)f32_to_bf16(pv.w) << 16);
+                *reinterpret_cast<uint2 *>(pb + i) = o;
+            }
+        } else {
+            for (long k = i; k < n; ++k) {
+                float pk = p[k], mk = m[k], vk = v[k];
+                adam1(pk, g[k], mk, vk, clip, wd, b1, b2, step_size, inv_bc2_sqrt, eps);
+                p[k] = pk; m[k] = mk; v[k] = vk;
+                if (pb) pb[k] = f32_to_bf16(pk);
+            }
+        }
+    }
+}
+
+__global__ void scale_by_clip_kernel(float *__restrict__ g, long n, const double *__restrict__ norm_sq, float max_norm)
+{
+    const float total = (float)sqrt(*norm_sq);
+    const float c = max_norm / (total + 1e-6f);
+    if (c >= 1.0f) return;
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) g[i] *= c;
+}
+
+}  // namespace yolo
+
+using namespace yolo;
+
+static inline unsigned grid_for(long n, int per_thread)
+{
+    long b = (n + 256L * per_thread - 1) / (256L * per_thread);
+    if (b > 2048) b = 2048;
+    if (b < 1) b = 1;
+    return (unsigned)b;
+}
+
+YOLO_API int yolo_sumsq_f32(const float *g, long n, double *acc, yolo_stream_t stream)
+{
+    if (!g || !acc || n < 0) return fail(YOLO_E_ARG, "yolo_sumsq_f32: bad argument");
+    if (n == 0) return 0;
+    if ((uintptr_t)g & 15) return fail(YOLO_E_UNSUPPORTED, "yolo_sumsq_f32: pointer must be 16-B aligned");
+    hipLaunchKernelGGL(sumsq_kernel, dim3(grid_for(n, 16)), dim3(256), 0, STRM(stream), g, n, acc);
+    return check_launch("yolo_sumsq_f32");
+}
+
+YOLO_API int yolo_adam_step(float *p, const float *g, float *m, float *v, long n, float lr, float beta1, float beta2, float eps, float weight_decay,
+                            long step, const double *norm_sq, float max_norm, void *p_bf16, yolo_stream_t stream)
+{
+    if (!p || !g || !m || !v || n < 0 || step < 1) return fail(YOLO_E_ARG, "yolo_adam_step: bad argument");
+    if (n == 0) return 0;
+    if (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) return fail(YOLO_E_UNSUPPORTED, "yolo_adam_step: pointers must be 16-B aligned");
+    const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+    const float step_size = (float)((double)lr / bc1);
+    const float inv_bc2_sqrt = (float)(1.0 / sqrt(bc2));
+    hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n, 8)), dim3(256), 0, STRM(stream), p, g, m, v, n, beta1, beta2, eps, weight_decay, step_size, inv_bc2_sqrt,
+                       norm_sq, max_norm, (bf16_t *)p_bf16);
+    return check_launch("yolo_adam_step");
+}
+
+YOLO_API int yolo_clip_scale_f32(float *g, long n, const double *norm_sq, float max_norm, yolo_stream_t stream)
+{
+    if (!g || !norm_sq || n < 0) return fail(YOLO_E_ARG, "yolo_clip_scale_f32: bad argument");
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(scale_by_clip_kernel, dim3(grid_for(n, 4)), dim3(256), 0, STRM(stream), g, n, norm_sq, max_norm);
+    return check_launch("yolo_clip_scale_f32");
+}

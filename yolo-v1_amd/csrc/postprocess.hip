@@ -154,93 +154,106 @@ __global__ void pairwise_iou_kernel(const double *__restrict__ a, int na, const 
 }
 
 // ------------------------------------------------------------------------------------------------
-// NMS: ONE wavefront per image, two boxes per lane (n <= 128).
+// NMS: one workgroup (4 wavefronts) per image, n <= 128 boxes.
 //   1. stable descending rank by confidence (ties keep scan order, like sorted(reverse=True))
-//   2. greedy sweep in rank order; the suppression set of a kept box is produced by two 64-lane
-//      ballots and OR-ed into wave-uniform "removed" masks -> no barriers, no atomics
-//   3. variant 1 re-orders the survivors by (first appearance of their class, rank)
+//   2. suppression matrix: row a (rank order) = the set of later same-class boxes b with
+//      !(IoU(a,b) < thr), produced by two 64-lane ballots; the rows are dealt to the 4 waves, so
+//      the fp64 IoU work (n^2/2 divisions) runs 256 lanes wide
+//   3. greedy sweep: wave 0 walks the rows with two wave-uniform 64-bit "removed" masks -- 128
+//      steps of bit arithmetic, no IoU, no barrier, no atomic
+//   4. variant 1 re-orders the survivors by (first appearance of their class, rank)
 // ------------------------------------------------------------------------------------------------
 template <int VARIANT>
-__global__ void __launch_bounds__(64) nms_kernel(const double *__restrict__ rec, const int *__restrict__ counts, int max_per_img,
-                                                 double thr, int *__restrict__ keep, int *__restrict__ keep_counts)
+__global__ void __launch_bounds__(256) nms_kernel(const double *__restrict__ rec, const int *__restrict__ counts, int max_per_img,
+                                                  double thr, int *__restrict__ keep, int *__restrict__ keep_counts)
 {
     const int img = blockIdx.x;
-    const int lane = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     int n = counts[img];
     if (n > max_per_img) n = max_per_img;
     const double *r = rec + (size_t)img * max_per_img * 6;
     int *kout = keep + (size_t)img * max_per_img;
 
     __shared__ double s_conf[128];
-    __shared__ double s_box[128][4];  // in rank order
-    __shared__ double s_cls[128];     // in rank order
-    __shared__ int s_orig[128];       // rank -> original index
-    __shared__ int s_kept[128];       // kept ranks, ascending
+    __shared__ double s_box[128][4];            // in rank order
+    __shared__ double s_cls[128];               // in rank order
+    __shared__ unsigned long long s_sup[128][2];  // suppression rows, rank order
+    __shared__ int s_orig[128];                 // rank -> original index
+    __shared__ int s_first[128];                // rank -> first rank holding the same class
+    __shared__ int s_kept[128];                 // kept ranks, ascending
+    __shared__ int s_nk;
 
-    for (int k = lane; k < n; k += 64) s_conf[k] = r[(size_t)k * 6 + 1];
+    if (tid < n) s_conf[tid] = r[(size_t)tid * 6 + 1];
     __syncthreads();
-    for (int k = lane; k < n; k += 64) {
-        const double c = s_conf[k];
+    if (tid < n) {
+        const double c = s_conf[tid];
         int rank = 0;
         for (int j = 0; j < n; ++j) {
             const double cj = s_conf[j];
-            rank += (cj > c) || (cj == c && j < k);
+            rank += (cj > c) || (cj == c && j < tid);
         }
-        s_orig[rank] = k;
-        s_cls[rank] = r[(size_t)k * 6 + 0];
-        s_box[rank][0] = r[(size_t)k * 6 + 2];
-        s_box[rank][1] = r[(size_t)k * 6 + 3];
-        s_box[rank][2] = r[(size_t)k * 6 + 4];
-        s_box[rank][3] = r[(size_t)k * 6 + 5];
+        s_orig[rank] = tid;
+        s_cls[rank] = r[(size_t)tid * 6 + 0];
+        s_box[rank][0] = r[(size_t)tid * 6 + 2];
+        s_box[rank][1] = r[(size_t)tid * 6 + 3];
+        s_box[rank][2] = r[(size_t)tid * 6 + 4];
+        s_box[rank][3] = r[(size_t)tid * 6 + 5];
     }
     __syncthreads();
 
-    // this lane's two boxes (ranks lane and lane+64)
+    // this lane's two boxes (ranks lane and lane+64), the same in every wave
     const int b0 = lane, b1 = lane + 64;
     double c0 = -1, x0 = 0, y0 = 0, w0 = 0, h0 = 0, c1 = -1, x1 = 0, y1 = 0, w1 = 0, h1 = 0;
     if (b0 < n) { c0 = s_cls[b0]; x0 = s_box[b0][0]; y0 = s_box[b0][1]; w0 = s_box[b0][2]; h0 = s_box[b0][3]; }
     if (b1 < n) { c1 = s_cls[b1]; x1 = s_box[b1][0]; y1 = s_box[b1][1]; w1 = s_box[b1][2]; h1 = s_box[b1][3]; }
-
-    unsigned long long removed0 = 0, removed1 = 0;  // wave-uniform
-    int nk = 0;
-    for (int a = 0; a < n; ++a) {
-        const bool dead = a < 64 ? ((removed0 >> a) & 1ull) : ((removed1 >> (a - 64)) & 1ull);
-        if (dead) continue;  // uniform branch
-        if (lane == 0) s_kept[nk] = a;
-        ++nk;
+    for (int a = wave; a < n; a += 4) {
         const double ca = s_cls[a], xa = s_box[a][0], ya = s_box[a][1], wa = s_box[a][2], ha = s_box[a][3];
         bool p0 = false, p1 = false;
         if (b0 > a && b0 < n && c0 == ca) p0 = !(iou_f64<VARIANT>(xa, ya, wa, ha, x0, y0, w0, h0) < thr);
         if (b1 > a && b1 < n && c1 == ca) p1 = !(iou_f64<VARIANT>(xa, ya, wa, ha, x1, y1, w1, h1) < thr);
-        removed0 |= __ballot(p0);
-        removed1 |= __ballot(p1);
+        const unsigned long long m0 = __ballot(p0), m1 = __ballot(p1);
+        if (lane == 0) { s_sup[a][0] = m0; s_sup[a][1] = m1; }
+    }
+    if (VARIANT == YOLO_NMS_METRICS && tid < n) {
+        const double ct = s_cls[tid];
+        int first = tid;
+        for (int j = 0; j < tid; ++j)
+            if (s_cls[j] == ct) { first = j; break; }
+        s_first[tid] = first;
     }
     __syncthreads();
 
-    if (VARIANT == YOLO_NMS_INFERENCE) {
-        for (int k = lane; k < nk; k += 64) kout[k] = s_orig[s_kept[k]];
-    } else {
-        // class buckets in first-appearance order of the sorted list (dict insertion order)
-        for (int k = lane; k < nk; k += 64) {
-            const int a = s_kept[k];
-            const double ca = s_cls[a];
-            int first = a;
-            for (int j = 0; j < a; ++j)
-                if (s_cls[j] == ca) { first = j; break; }
-            // position = number of survivors with a smaller (first, rank) key
-            int pos = 0;
-            for (int q = 0; q < nk; ++q) {
-                const int aq = s_kept[q];
-                const double cq = s_cls[aq];
-                int fq = aq;
-                for (int j = 0; j < aq; ++j)
-                    if (s_cls[j] == cq) { fq = j; break; }
-                pos += (fq < first) || (fq == first && aq < a);
-            }
-            kout[pos] = s_orig[a];
+    if (wave == 0) {
+        unsigned long long removed0 = 0, removed1 = 0;  // wave-uniform
+        int nk = 0;
+        for (int a = 0; a < n; ++a) {
+            const bool dead = a < 64 ? ((removed0 >> a) & 1ull) : ((removed1 >> (a - 64)) & 1ull);
+            if (dead) continue;
+            if (lane == 0) s_kept[nk] = a;
+            ++nk;
+            removed0 |= s_sup[a][0];
+            removed1 |= s_sup[a][1];
         }
+        if (lane == 0) s_nk = nk;
     }
-    if (lane == 0) keep_counts[img] = nk;
+    __syncthreads();
+    const int nk = s_nk;
+
+    if (VARIANT == YOLO_NMS_INFERENCE) {
+        if (tid < nk) kout[tid] = s_orig[s_kept[tid]];
+    } else if (tid < nk) {
+        // class buckets in first-appearance order of the sorted list (dict insertion order):
+        // position = number of survivors with a smaller (first, rank) key
+        const int a = s_kept[tid], first = s_first[a];
+        int pos = 0;
+        for (int q = 0; q < nk; ++q) {
+            const int aq = s_kept[q], fq = s_first[aq];
+            pos += (fq < first) || (fq == first && aq < a);
+        }
+        kout[pos] = s_orig[a];
+    }
+    if (tid == 0) keep_counts[img] = nk;
 }
 
 }  // namespace yolo
@@ -273,9 +286,9 @@ YOLO_API int yolo_nms(const double *rec, const int32_t *counts, int N, int max_p
     if (variant != YOLO_NMS_INFERENCE && variant != YOLO_NMS_METRICS) return fail(YOLO_E_ARG, "yolo_nms: variant %d", variant);
     if (N == 0) return 0;
     if (variant == YOLO_NMS_INFERENCE)
-        hipLaunchKernelGGL(nms_kernel<YOLO_NMS_INFERENCE>, dim3(N), dim3(64), 0, STRM(stream), rec, counts, max_per_img, thr, keep, keep_counts);
+        hipLaunchKernelGGL(nms_kernel<YOLO_NMS_INFERENCE>, dim3(N), dim3(256), 0, STRM(stream), rec, counts, max_per_img, thr, keep, keep_counts);
     else
-        hipLaunchKernelGGL(nms_kernel<YOLO_NMS_METRICS>, dim3(N), dim3(64), 0, STRM(stream), rec, counts, max_per_img, thr, keep, keep_counts);
+        hipLaunchKernelGGL(nms_kernel<YOLO_NMS_METRICS>, dim3(N), dim3(256), 0, STRM(stream), rec, counts, max_per_img, thr, keep, keep_counts);
     return check_launch("yolo_nms");
 }
 

@@ -178,15 +178,20 @@ __global__ void __launch_bounds__(256, 2) wgrad_kernel(const WgradParams p)
         }
 }
 
-// db[c] += sum_p dy[p][c]  (bias gradient): each workgroup sums a slab of pixels for 8*64 channels
-__global__ void __launch_bounds__(256) colsum_kernel(const bf16_t *__restrict__ dy, long P, int px_stride, int C, long p_per_blk, float *__restrict__ db)
+// db[c] += sum_p dy[p][c]  (bias gradient).  HBM-bound column sum: a workgroup covers w <= 256
+// 8-channel chunks (one 16-B load per thread) x R = 256/w pixel rows per pass, so every wave reads
+// whole contiguous pixel rows whatever the channel count; LDS reduction over R, one fp32 atomic per
+// channel per workgroup.
+__global__ void __launch_bounds__(256) colsum_kernel(const bf16_t *__restrict__ dy, long P, int px_stride, int C, int w, long p_per_blk, float *__restrict__ db)
 {
-    const int c8 = blockIdx.x * 64 + (threadIdx.x & 63);  // 8-channel chunk
-    const int sub = threadIdx.x >> 6;                      // 4 pixel phases
+    const int nchunks = (C + 7) >> 3;
+    const int R = 256 / w;
+    const int col = threadIdx.x % w, r = threadIdx.x / w;
+    const int c8 = blockIdx.x * w + col;
     const long pbeg = (long)blockIdx.y * p_per_blk, pend = min(P, pbeg + p_per_blk);
     float s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (c8 * 8 < C) {
-        for (long pr = pbeg + sub; pr < pend; pr += 4) {
+    if (r < R && c8 < nchunks) {
+        for (long pr = pbeg + r; pr < pend; pr += R) {
             const uint4 v = *reinterpret_cast<const uint4 *>(dy + pr * px_stride + c8 * 8);
             s[0] += __uint_as_float(v.x << 16); s[1] += __uint_as_float(v.x & 0xffff0000u);
             s[2] += __uint_as_float(v.y << 16); s[3] += __uint_as_float(v.y & 0xffff0000u);
@@ -194,14 +199,15 @@ __global__ void __launch_bounds__(256) colsum_kernel(const bf16_t *__restrict__ 
             s[6] += __uint_as_float(v.w << 16); s[7] += __uint_as_float(v.w & 0xffff0000u);
         }
     }
-    __shared__ float red[4][64][9];
+    __shared__ float red[256][9];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) red[sub][threadIdx.x & 63][k] = s[k];
+    for (int k = 0; k < 8; ++k) red[threadIdx.x][k] = s[k];
     __syncthreads();
-    if (sub == 0 && c8 * 8 < C) {
+    if (r == 0 && c8 < nchunks) {
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-            const float t = red[0][threadIdx.x][k] + red[1][threadIdx.x][k] + red[2][threadIdx.x][k] + red[3][threadIdx.x][k];
+            float t = 0.0f;
+            for (int rr = 0; rr < R; ++rr) t += red[rr * w + col][k];
             if (c8 * 8 + k < C) atomicAdd(db + c8 * 8 + k, t);
         }
     }
@@ -245,12 +251,15 @@ YOLO_API int yolo_wgrad(const yolo_wgrad_desc *d, const void *x, const void *dy,
         if (int rc = check_launch("yolo_wgrad")) return rc;
     }
     if (db) {
-        const int chunks = (d->Cout + 7) / 8;
-        const int gx = (chunks + 63) / 64;
-        int gy = (int)std::min<long>(1024, (d->P + 255) / 256);
+        const int nchunks = (d->Cout + 7) / 8;
+        const int w = nchunks < 256 ? nchunks : 256;
+        const int R = 256 / w;
+        const int gx = (nchunks + w - 1) / w;
+        long gy = d->P / ((long)R * 32);
+        if (gy > 2048 / gx) gy = 2048 / gx;
         if (gy < 1) gy = 1;
         const long per = (d->P + gy - 1) / gy;
-        hipLaunchKernelGGL(colsum_kernel, dim3(gx, gy), dim3(256), 0, s, (const bf16_t *)dy, (long)d->P, d->dy_px_stride, d->Cout, per, db);
+        hipLaunchKernelGGL(colsum_kernel, dim3(gx, (unsigned)gy), dim3(256), 0, s, (const bf16_t *)dy, (long)d->P, d->dy_px_stride, d->Cout, w, per, db);
         if (int rc = check_launch("yolo_wgrad(bias)")) return rc;
     }
     return 0;

@@ -84,6 +84,9 @@ _SIGS = {
     "yolo_transpose_f32_to_bf16": [c_void_p, c_int, c_int, c_void_p, c_int, c_void_p],
     "yolo_cast_f32_to_bf16": [c_void_p, c_long, c_void_p, c_void_p],
     "yolo_cast_bf16_to_f32": [c_void_p, c_long, c_void_p, c_void_p],
+    "yolo_sumsq_f32": [c_void_p, c_long, c_void_p, c_void_p],
+    "yolo_adam_step": [c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_float, c_float, c_float, c_float, c_float, c_long, c_void_p, c_float, c_void_p, c_void_p],
+    "yolo_clip_scale_f32": [c_void_p, c_long, c_void_p, c_float, c_void_p],
     "yolo_bias_lrelu_rows": [c_void_p, c_void_p, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p],
 }
 
