@@ -31,6 +31,7 @@ struct WgradParams {
     const bf16_t *x;
     const bf16_t *dy;
     float *dw;
+    float *db;              // optional: bias gradient, accumulated by the (tap 0, ci-tile 0) workgroups
     long P;                 // flat pixel slots to reduce over
     long p_per_split;
     int dy_px_stride, x_px_stride;
@@ -52,7 +53,12 @@ constexpr int WG_LDS_BYTES = 2 * WG_STAGE_BYTES;  // double buffered: 64 KB
 
 __global__ void __launch_bounds__(256, 2) wgrad_kernel(const WgradParams p)
 {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+    // Two SEPARATE LDS objects, one per pipeline stage, and a K loop unrolled by two so that every
+    // access names its stage statically: hipcc then knows the LDS-DMA writes of stage t+1 cannot alias
+    // the transposing reads of stage t and does not drain vmcnt(0) in front of the first ds_read
+    // (with one array and a runtime stage index it serialised load and compute).
+    __shared__ __attribute__((aligned(16))) char bufA[WG_STAGE_BYTES];
+    __shared__ __attribute__((aligned(16))) char bufB[WG_STAGE_BYTES];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wco = wave >> 1, wci = wave & 1;
@@ -94,8 +100,7 @@ __global__ void __launch_bounds__(256, 2) wgrad_kernel(const WgradParams p)
     }
     const bf16_t *zline = reinterpret_cast<const bf16_t *>(g_zero_line) + (lane & 15) * 8;
 
-    auto stage = [&](int buf, long pb) {
-        char *sb = smem + buf * WG_STAGE_BYTES;
+    auto stage = [&](char *sb, long pb) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const long pr = pb + row_of[i];
@@ -127,15 +132,13 @@ __global__ void __launch_bounds__(256, 2) wgrad_kernel(const WgradParams p)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
+    // bias gradient rides along: the dy fragments of the (tap 0, ci-tile 0) workgroups cover every
+    // (pixel, co) exactly once over the grid, so summing them costs no extra HBM pass
+    const bool do_bias = p.db != nullptr && tap == 0 && ci_tile == 0 && wci == 0;
+    float bsum[2] = {0.0f, 0.0f};
+
     typedef __attribute__((address_space(3))) s16x4 *lds_s16x4;
-    if (pbeg < pend) stage(0, pbeg);
-    int it = 0;
-    for (long pb = pbeg; pb < pend; pb += WG_BP, ++it) {
-        const int buf = it & 1;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (pb + WG_BP < pend) stage(buf ^ 1, pb + WG_BP);
-        char *sb = smem + buf * WG_STAGE_BYTES;
+    auto compute = [&](const char *sb) {
 #pragma unroll
         for (int ks = 0; ks < WG_BP / 16; ++ks) {
             bf16x8 af[2], bfr[2];
@@ -144,6 +147,10 @@ __global__ void __launch_bounds__(256, 2) wgrad_kernel(const WgradParams p)
                 const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(sb + a_rd[t] + ks * 4096));
                 const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(sb + a_rd[t] + ks * 4096 + 1024));
                 af[t] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+                if (do_bias) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) bsum[t] += __uint_as_float(((unsigned)(unsigned short)lo[e]) << 16) + __uint_as_float(((unsigned)(unsigned short)hi[e]) << 16);
+                }
             }
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
@@ -155,6 +162,27 @@ __global__ void __launch_bounds__(256, 2) wgrad_kernel(const WgradParams p)
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+        }
+    };
+    if (pbeg < pend) stage(bufA, pbeg);
+    for (long pb = pbeg; pb < pend; pb += 2 * WG_BP) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();  // stage A landed for every wave; stage B is free
+        if (pb + WG_BP < pend) stage(bufB, pb + WG_BP);
+        compute(bufA);
+        if (pb + WG_BP >= pend) break;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (pb + 2 * WG_BP < pend) stage(bufA, pb + 2 * WG_BP);
+        compute(bufB);
+    }
+
+    if (do_bias) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const float tot = bsum[t] + __shfl_xor(bsum[t], 32, 64);  // the two k-halves of each co row
+            const int co = co0 + wco * 64 + t * 32 + (lane & 31);
+            if (lane < 32 && co < p.Cout) atomicAdd(p.db + co, tot);
         }
     }
 
@@ -188,16 +216,27 @@ __global__ void __launch_bounds__(256) colsum_kernel(const bf16_t *__restrict__ 
     const int R = 256 / w;
     const int col = threadIdx.x % w, r = threadIdx.x / w;
     const int c8 = blockIdx.x * w + col;
-    const long pbeg = (long)blockIdx.y * p_per_blk, pend = min(P, pbeg + p_per_blk);
+    // grid-stride over pixel rows: all workgroups sweep the buffer together (DRAM-page friendly),
+    // 4 independent 16-B loads in flight per thread
+    const long step = (long)gridDim.y * R;
     float s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    auto acc8 = [&](const uint4 &v) {
+        s[0] += __uint_as_float(v.x << 16); s[1] += __uint_as_float(v.x & 0xffff0000u);
+        s[2] += __uint_as_float(v.y << 16); s[3] += __uint_as_float(v.y & 0xffff0000u);
+        s[4] += __uint_as_float(v.z << 16); s[5] += __uint_as_float(v.z & 0xffff0000u);
+        s[6] += __uint_as_float(v.w << 16); s[7] += __uint_as_float(v.w & 0xffff0000u);
+    };
     if (r < R && c8 < nchunks) {
-        for (long pr = pbeg + r; pr < pend; pr += R) {
-            const uint4 v = *reinterpret_cast<const uint4 *>(dy + pr * px_stride + c8 * 8);
-            s[0] += __uint_as_float(v.x << 16); s[1] += __uint_as_float(v.x & 0xffff0000u);
-            s[2] += __uint_as_float(v.y << 16); s[3] += __uint_as_float(v.y & 0xffff0000u);
-            s[4] += __uint_as_float(v.z << 16); s[5] += __uint_as_float(v.z & 0xffff0000u);
-            s[6] += __uint_as_float(v.w << 16); s[7] += __uint_as_float(v.w & 0xffff0000u);
+        const bf16_t *base = dy + c8 * 8;
+        long pr = (long)blockIdx.y * R + r;
+        for (; pr + 3 * step < P; pr += 4 * step) {
+            const uint4 v0 = *reinterpret_cast<const uint4 *>(base + pr * px_stride);
+            const uint4 v1 = *reinterpret_cast<const uint4 *>(base + (pr + step) * px_stride);
+            const uint4 v2 = *reinterpret_cast<const uint4 *>(base + (pr + 2 * step) * px_stride);
+            const uint4 v3 = *reinterpret_cast<const uint4 *>(base + (pr + 3 * step) * px_stride);
+            acc8(v0); acc8(v1); acc8(v2); acc8(v3);
         }
+        for (; pr < P; pr += step) acc8(*reinterpret_cast<const uint4 *>(base + pr * px_stride));
     }
     __shared__ float red[256][9];
 #pragma unroll
@@ -225,14 +264,8 @@ YOLO_API int yolo_wgrad(const yolo_wgrad_desc *d, const void *x, const void *dy,
         return fail(YOLO_E_UNSUPPORTED, "yolo_wgrad: pixel strides must be multiples of 8 elements and cover the channels");
     hipStream_t s = STRM(stream);
     if (dw) {
-        static bool attr_done = false;
-        if (!attr_done) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&wgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, WG_LDS_BYTES);
-            if (e != hipSuccess) return fail((int)e, "yolo_wgrad: hipFuncSetAttribute: %s", hipGetErrorString(e));
-            attr_done = true;
-        }
         WgradParams p{};
-        p.x = (const bf16_t *)x; p.dy = (const bf16_t *)dy; p.dw = dw;
+        p.x = (const bf16_t *)x; p.dy = (const bf16_t *)dy; p.dw = dw; p.db = db;
         p.P = d->P;
         p.dy_px_stride = d->dy_px_stride; p.x_px_stride = d->x_px_stride;
         p.Cout = d->Cout; p.Cin = d->Cin;
@@ -247,10 +280,10 @@ YOLO_API int yolo_wgrad(const yolo_wgrad_desc *d, const void *x, const void *dy,
         const int splits = (int)((d->P + per - 1) / per);
         p.p_per_split = per;
         p.atomic = (splits > 1 || d->accumulate) ? 1 : 0;
-        hipLaunchKernelGGL(wgrad_kernel, dim3(p.n_co_tiles * p.n_ci_tiles * p.ntaps, splits), dim3(256), WG_LDS_BYTES, s, p);
+        hipLaunchKernelGGL(wgrad_kernel, dim3(p.n_co_tiles * p.n_ci_tiles * p.ntaps, splits), dim3(256), 0, s, p);
         if (int rc = check_launch("yolo_wgrad")) return rc;
     }
-    if (db) {
+    if (db && !dw) {
         const int nchunks = (d->Cout + 7) / 8;
         const int w = nchunks < 256 ? nchunks : 256;
         const int R = 256 / w;
