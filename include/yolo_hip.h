@@ -130,6 +130,8 @@ typedef struct yolo_igemm_desc {
     /* aux addressing for YOLO_EPI_MUL_DLRELU (same form as the output addressing) */
     int64_t aux_img_stride;
     int32_t aux_row_stride, aux_px_stride, aux_off;
+    int32_t tile_hint;      /* 0 = let the library pick the tile configuration; 1: 128x128, 2: 256x128
+                               (8 waves, 3 stages), 3: 128x64, 4: 64x128  (tuning / tests)             */
 } yolo_igemm_desc;
 
 #define YOLO_EPI_NONE 0        /* out = acc                                                        */

@@ -208,3 +208,25 @@ def test_layout_roundtrip():
     assert torch.equal(back, _bf(x))
     v = a.view()
     assert v[:, 0].abs().sum() == 0 and v[:, -1].abs().sum() == 0 and v[:, :, 0].abs().sum() == 0 and v[:, :, -1].abs().sum() == 0
+
+
+@pytest.mark.parametrize("hint", [1, 2, 3, 4])
+def test_every_tile_configuration(hint):
+    """the same 3x3 / 1x1 chain through each yolo_igemm tile configuration (128x128, 256x128 8-wave
+    3-stage ring, 128x64, 64x128), forward and data-gradient, with ragged pixel and channel tiles."""
+    from yolo import engine
+    torch.manual_seed(4)
+    mods = nn.Sequential(
+        nn.Conv2d(64, 256, 3, 1, 1), nn.LeakyReLU(0.1),
+        nn.Conv2d(256, 320, 1), nn.LeakyReLU(0.1),
+        nn.Conv2d(320, 512, 3, 1, 1), nn.LeakyReLU(0.1))
+    x = torch.randn(3, 64, 13, 17)
+    gy = torch.randn(3, 512, 13, 17)
+    engine.TILE_HINT = hint
+    try:
+        yc, yg, gc, gg = _run_both(mods, x, gy)
+    finally:
+        engine.TILE_HINT = 0
+    _close(yg, yc, 6.0, f"hint {hint} y")
+    for i, (a, b) in enumerate(zip(gg, gc)):
+        _close(a, b, 12.0, f"hint {hint} grad {i}", frac=0.01)

@@ -1,0 +1,237 @@
+"""CPU: the module surface behaves like the reference's (restates the assertions of the reference's
+own suite: tests/test_backbone.py, tests/test_yolo.py, tests/test_metrics.py of mattiaskvist/yolo-v1)
+and the host logic (numpy post-processing, mAP) agrees with the reference fixtures."""
+
+import json
+import os
+import tempfile
+
+import numpy as np
+import pytest
+import torch
+from PIL import Image
+
+import synth
+from yolo import (Backbone, BoundingBox, Detection, DetectionHead, YOLOLoss, YOLOv1, YOLOv1Backbone, mAPMetric)
+from yolo.inference import YOLOInference
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.fixture(scope="module")
+def model():
+    torch.manual_seed(0)
+    return YOLOv1(num_classes=20, S=7, B=2).eval()
+
+
+@pytest.fixture(scope="module")
+def engine(model):
+    return YOLOInference(model, device="cpu")
+
+
+@pytest.fixture()
+def sample_image():
+    with tempfile.NamedTemporaryFile(suffix=".jpg", delete=False) as tmp:
+        Image.new("RGB", (448, 448), color="red").save(tmp.name)
+    yield tmp.name
+    os.unlink(tmp.name)
+
+
+# ---------------------------------------------------------------- models (reference tests/test_backbone.py)
+def test_backbone_base_raises():
+    with pytest.raises(NotImplementedError):
+        Backbone()(torch.randn(1, 3, 448, 448))
+
+
+def test_yolov1_shapes_and_state_dict(model):
+    with torch.no_grad():
+        y = model(torch.randn(2, 3, 448, 448))
+        f = model.backbone(torch.randn(1, 3, 448, 448))
+    assert y.shape == (2, 7, 7, 30) and not torch.isnan(y).any()
+    assert f.shape == (1, 1024, 7, 7)
+    assert isinstance(model.backbone, YOLOv1Backbone)
+    assert (model.num_classes, model.S, model.B) == (20, 7, 2)
+    keys = list(model.state_dict().keys())
+    conv_idx = [0, 3, 6, 8, 10, 12, 15, 17, 19, 21, 23, 25, 27, 29, 31, 33, 36, 38, 40, 42, 44, 46, 48, 50]
+    want = [f"backbone.features.{i}.{p}" for i in conv_idx for p in ("weight", "bias")] + ["head.1.weight", "head.1.bias", "head.4.weight", "head.4.bias"]
+    assert keys == want                                   # SURVEY.md 8b checkpoint contract
+    assert sum(p.numel() for p in model.parameters()) == 271_703_550
+    assert model.state_dict()["head.1.weight"].shape == (4096, 50176)
+
+
+def test_constructor_variants():
+    for S in (7, 14):
+        assert YOLOv1(S=S).S == S
+    class Custom(Backbone):
+        def forward(self, x):
+            return x
+    with pytest.raises(ValueError):
+        YOLOv1(backbone=Custom())
+    m = YOLOv1(backbone=Custom(), detection_head=torch.nn.Identity())
+    assert isinstance(m.head, torch.nn.Identity)
+
+
+def test_detection_head_shapes():
+    head = DetectionHead(64, num_classes=20, S=7, B=2)      # narrow input: same structure, affordable on CPU
+    assert list(head.state_dict().keys())[:2] == ["conv_layers.0.weight", "conv_layers.0.bias"]
+    assert "fc_layers.4.bias" in head.state_dict()
+    with torch.no_grad():
+        assert head(torch.randn(2, 64, 14, 14)).shape == (2, 7, 7, 30)
+
+
+def test_gradient_reaches_input(model):
+    x = torch.randn(1, 3, 448, 448, requires_grad=True)
+    model(x).sum().backward()
+    assert x.grad is not None and not torch.isnan(x.grad).any()
+
+
+def test_loads_the_reference_fixture_weights_and_reproduces_its_output(model):
+    """same state_dict + same input as the run of the reference that produced backbone_full.npz"""
+    import copy
+    m = copy.deepcopy(model)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in synth.yolov1_state_dict().items()}, strict=True)
+    g = np.load(os.path.join(GOLDEN, "backbone_full.npz"))
+    with torch.no_grad():
+        y = m.eval()(torch.from_numpy(synth.synth_images(1, 0)))
+    np.testing.assert_allclose(y.numpy(), g["y"], rtol=1e-4, atol=1e-4)
+
+
+# ---------------------------------------------------------------- inference (reference tests/test_yolo.py)
+def test_inference_engine(engine, model, sample_image):
+    assert engine.model is model and engine.device == "cpu" and hasattr(engine, "transform") and not engine.model.training
+    lo = engine.predict(sample_image, conf_threshold=0.1, nms_threshold=0.4)
+    hi = engine.predict(sample_image, conf_threshold=0.9, nms_threshold=0.4)
+    assert isinstance(lo, list) and len(hi) <= len(lo)
+    with pytest.raises(FileNotFoundError):
+        engine.predict("nonexistent_image.jpg")
+    t = engine.preprocess_image(engine.load_image(sample_image))
+    assert t.shape == (1, 3, 448, 448) and -5 <= t.min() and t.max() <= 5
+
+
+def test_parse_predictions_kat(engine):
+    pred = torch.zeros(7, 7, 30)
+    pred[2, 3, 0:5] = torch.tensor([0.5, 0.5, 0.3, 0.3, 0.9])
+    pred[2, 3, 10] = 0.8
+    dets = engine.parse_predictions(pred, conf_threshold=0.5)
+    assert len(dets) == 1 and isinstance(dets[0], Detection) and isinstance(dets[0].class_id, int)
+    assert dets[0].confidence == 0.7199999916553494 and dets[0].class_name == "class_0"
+    assert dets[0].bbox.x == pytest.approx(3.5 / 7) and dets[0].bbox.y == pytest.approx(2.5 / 7)
+    assert len(engine.parse_predictions(pred, conf_threshold=0.9)) == 0
+    bad = pred.clone()
+    bad[2, 3, 2] = -0.3                                  # negative width -> pydantic ValidationError like the reference
+    with pytest.raises(ValueError):
+        engine.parse_predictions(bad, conf_threshold=0.5)
+
+
+def test_bounding_box():
+    b = BoundingBox(x=0.5, y=0.5, width=0.4, height=0.6)
+    assert b.area == pytest.approx(0.24) and b.to_corners() == pytest.approx((0.3, 0.2, 0.7, 0.8))
+    px = b.to_pixel_coords(640, 480)
+    assert all(abs(a - e) <= 1 for a, e in zip(px, (192, 96, 448, 384)))
+    with pytest.raises(ValueError):
+        BoundingBox(x=1.5, y=0.5, width=0.3, height=0.3)
+    r = BoundingBox.from_corners(0.1, 0.2, 0.5, 0.8)
+    assert (r.x, r.y, r.width, r.height) == pytest.approx((0.3, 0.5, 0.4, 0.6))
+    assert str(b) == "(0.30, 0.20, 0.70, 0.80)"
+
+
+def test_iou_and_nms_kats(engine):
+    box = BoundingBox(x=0.5, y=0.5, width=0.3, height=0.3)
+    assert engine.iou(box, box) == pytest.approx(1.0, abs=1e-4)
+    assert engine.iou(BoundingBox(x=0.2, y=0.2, width=0.1, height=0.1), BoundingBox(x=0.8, y=0.8, width=0.1, height=0.1)) == pytest.approx(0.0, abs=1e-5)
+    a, b = BoundingBox(x=0.3, y=0.3, width=0.2, height=0.2), BoundingBox(x=0.4, y=0.4, width=0.2, height=0.2)
+    assert 0 < engine.iou(a, b) < 1 and engine.iou(a, b) == pytest.approx(engine.iou(b, a), abs=1e-5)
+
+    def det(c, conf, x, y, w, h):
+        return Detection(class_id=c, class_name="t", confidence=conf, bbox=BoundingBox(x=x, y=y, width=w, height=h))
+    with pytest.warns(DeprecationWarning):
+        assert engine.non_max_suppression([], iou_threshold=0.5) == []
+    one = [det(0, 0.9, 0.5, 0.5, 0.3, 0.3)]
+    assert engine.non_max_suppression(one, nms_threshold=0.5) == one
+    two = [det(0, 0.9, 0.5, 0.5, 0.3, 0.3), det(0, 0.7, 0.52, 0.52, 0.3, 0.3)]
+    kept = engine.non_max_suppression(two, nms_threshold=0.3)
+    assert len(kept) == 1 and kept[0].confidence == 0.9
+    assert len(engine.non_max_suppression([two[0], det(1, 0.8, 0.52, 0.52, 0.3, 0.3)], nms_threshold=0.3)) == 2
+    assert len(engine.non_max_suppression([det(0, 0.9, 0.2, 0.2, 0.1, 0.1), det(0, 0.8, 0.8, 0.8, 0.1, 0.1)])) == 2
+
+
+def test_cpu_postprocessing_matches_reference_fixtures():
+    """the numpy decode / NMS (CPU-device path of the package) vs post_cases.npz, bit-exact"""
+    from yolo import _post_cpu as P
+    g = np.load(os.path.join(GOLDEN, "post_cases.npz"))
+    for name in [str(n) for n in g["names"]]:
+        pred = g[f"{name}__pred"]
+        ct, nt = g[f"{name}__thr"]
+        for n in range(pred.shape[0]):
+            rec = P.decode(pred[n], ct, 7, 2)
+            assert np.array_equal(rec, g[f"{name}__m{n}_dec"]), (name, n)
+            assert np.array_equal(P.nms(rec, nt, P.METRICS), g[f"{name}__m{n}_keep"]), (name, n)
+            if f"{name}__i{n}_keep" in g:
+                assert np.array_equal(P.nms(rec, nt, P.INFERENCE), g[f"{name}__i{n}_keep"]), (name, n)
+    for r, m, i in zip(g["ioupairs__in"], g["ioupairs__metrics"], g["ioupairs__inference"]):
+        assert P.iou_scalar(r[:4], r[4:], P.METRICS) == m and P.iou_scalar(r[:4], r[4:], P.INFERENCE) == i
+
+
+# ---------------------------------------------------------------- metrics (reference tests/test_metrics.py)
+def test_metric_helpers_and_kats():
+    m = mAPMetric(num_classes=20)
+    assert (m.S, m.B, m.conf_threshold, m.nms_threshold, len(m.iou_thresholds)) == (7, 2, 0.01, 0.4, 10)
+    assert m._calculate_iou((0.5, 0.5, 0.2, 0.2), (0.5, 0.5, 0.2, 0.2)) == pytest.approx(1.0, abs=1e-5)
+    assert m._calculate_iou((0.2, 0.2, 0.1, 0.1), (0.8, 0.8, 0.1, 0.1)) == 0.0
+    assert m._calculate_iou((0.5, 0.5, 0.0, 0.0), (0.5, 0.5, 0.0, 0.0)) == 0.0
+    m = mAPMetric(num_classes=20, nms_threshold=0.5)
+    kept = m._apply_nms([(0, 0.9, (0.5, 0.5, 0.2, 0.2)), (0, 0.8, (0.52, 0.52, 0.2, 0.2)), (1, 0.85, (0.7, 0.7, 0.15, 0.15))])
+    assert len(kept) == 2 and [d[1] for d in kept if d[0] == 0] == [0.9]
+    m = mAPMetric(num_classes=20, conf_threshold=0.1)
+    pred = torch.zeros(7, 7, 30)
+    pred[3, 3, 0:5] = torch.tensor([0.5, 0.5, 0.3, 0.3, 0.9])
+    pred[3, 3, 10] = 1.0
+    dets = m._parse_predictions(pred)
+    assert len(dets) == 1 and dets[0][0] == 0 and dets[0][1] > 0.1
+    gts = m._parse_ground_truth(pred)
+    assert len(gts) == 1 and gts[0][0] == 0
+
+
+def test_perfect_and_empty_predictions():
+    m = mAPMetric(num_classes=20, iou_thresholds=[0.5])
+    p = torch.zeros(5, 7, 7, 30)
+    p[:, 3, 3, 0:5] = torch.tensor([0.5, 0.5, 0.3, 0.3, 1.0])
+    p[:, 3, 3, 10] = 1.0
+    m.update(p, p.clone())
+    r = m.compute()
+    for k in ("AP50_class_0", "AP50:95_class_0", "precision", "recall"):
+        assert r[k] == pytest.approx(1.0, abs=1e-5)
+    m = mAPMetric(num_classes=20, conf_threshold=0.9)
+    q = torch.zeros(2, 7, 7, 30)
+    q[:, 3, 3, 4] = 0.1
+    m.update(q, p[:2])
+    assert m.compute()["recall"] == 0.0
+    assert mAPMetric(20).compute() == {"mAP50:95": 0.0, "mAP50": 0.0, "mAP75": 0.0, "precision": 0.0, "recall": 0.0}
+
+
+def test_map_matches_reference_fixture():
+    d = np.load(os.path.join(GOLDEN, "map_case.npz"))
+    ref = json.load(open(os.path.join(GOLDEN, "map_case.json")))
+    m = mAPMetric(20, conf_threshold=0.05, nms_threshold=0.4)
+    m.update(torch.from_numpy(d["pred"]), torch.from_numpy(d["tgt"]))
+    res = m.compute()
+    assert set(res) == set(ref)
+    for k, v in ref.items():
+        assert float(res[k]) == pytest.approx(v, abs=1e-12), k
+
+
+# ---------------------------------------------------------------- loss (CPU-device path vs reference fixtures)
+def test_cpu_loss_matches_reference_fixtures():
+    g = np.load(os.path.join(GOLDEN, "loss_cases.npz"))
+    for name in [str(n) for n in g["names"]]:
+        lc, ln = (float(v) for v in g[f"{name}__lambdas"])
+        p = torch.from_numpy(g[f"{name}__pred"]).requires_grad_(True)
+        total, d = YOLOLoss(lambda_coord=lc, lambda_noobj=ln)(p, torch.from_numpy(g[f"{name}__tgt"]))
+        total.backward()
+        got = np.array([d[k] for k in ("total", "coord", "conf_obj", "conf_noobj", "class")])
+        np.testing.assert_allclose(got, g[f"{name}__out5"], rtol=1e-5, atol=1e-6, err_msg=name)
+        np.testing.assert_allclose(p.grad.numpy(), g[f"{name}__dpred"], rtol=1e-4, atol=1e-6, err_msg=name)
+    t = torch.zeros(1, 7, 7, 30)
+    t[0, 1, 1, 14] = 1.0
+    with pytest.raises(RuntimeError):
+        YOLOLoss()(torch.zeros(1, 7, 7, 30), t)

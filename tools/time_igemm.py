@@ -1,0 +1,54 @@
+#!/usr/bin/env python3
+"""micro-benchmark: yolo_igemm forward on every YOLOv1 conv layer shape at N=64, per tile configuration."""
+import ctypes, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "yolo-v1_amd")); sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+import torch
+import synth
+from yolo._hip import lib, check, ptr, stream, IgemmDesc, EPI_BIAS_LRELU
+from yolo.engine import Act
+
+N = int(os.environ.get("N", 64))
+hints = [int(h) for h in os.environ.get("HINTS", "0,1,2,3,4").split(",")]
+dev = torch.device("cuda")
+h = 448
+tot = {k: 0.0 for k in hints}
+for item in synth.YOLOV1_BACKBONE_CFG:
+    if item == "M":
+        h //= 2
+        continue
+    idx, (co, ci, k, s, p) = item
+    hin = h
+    h = (h + 2 * p - k) // s + 1
+    if idx == 0:
+        continue
+    x = Act(N, hin, hin, ci, 1, dev); y = Act(N, h, h, co, 1, dev)
+    x.t.normal_()
+    w = torch.randn((co, k, k, ci), device=dev).to(torch.bfloat16)
+    b = torch.randn((co,), device=dev)
+    d = IgemmDesc()
+    d.N, d.Ho, d.Wo = N, h, h
+    d.in_img_stride, d.in_row_stride, d.in_px_stride = x.img_stride, x.row_stride, x.px_stride
+    d.in_off = x.interior_off(p); d.stride = s; d.KH = d.KW = k; d.tap_len = ci; d.Cout = co
+    d.out_img_stride, d.out_row_stride, d.out_px_stride, d.out_off = y.img_stride, y.row_stride, y.px_stride, y.interior_off()
+    d.epilogue, d.slope, d.out_fp32, d.split_k = EPI_BIAS_LRELU, 0.1, 0, 1
+    fl = 2.0 * N * h * h * co * ci * k * k
+    line = f"idx {idx:2d} co {co:4d} ci {ci:4d} k {k} s {s} out {h:3d} M {N*h*h:7d} K {ci*k*k:5d} |"
+    for hint in hints:
+        d.tile_hint = hint
+        try:
+            for _ in range(2):
+                check(lib().yolo_igemm(ctypes.byref(d), x.p, ptr(w), ptr(b), None, y.p, stream()))
+            e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(5):
+                check(lib().yolo_igemm(ctypes.byref(d), x.p, ptr(w), ptr(b), None, y.p, stream()))
+            e1.record(); torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / 5
+            tot[hint] += ms
+            line += f" h{hint}: {ms:6.3f} ms {fl/ms/1e9:6.0f} TF |"
+        except RuntimeError as e:
+            line += f" h{hint}: n/a |"
+    print(line)
+    del x, y
+print("totals (ms):", {k: round(v, 3) for k, v in tot.items()})

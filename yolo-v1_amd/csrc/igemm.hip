@@ -10,13 +10,16 @@
 //     previous LeakyReLU's derivative),
 //   * Linear forward / data-gradient of the FC head (models.py:239-245) as a 1x1 conv on a 1x1 image.
 //
-// Structure (per 256-thread workgroup = 4 wave64, one per SIMD):
+// Structure (per workgroup of WCO x WPX wave64):
 //   tile  TCO output channels x TPX output pixels, K step BK (one tap, BK channels)
-//   LDS   2 stages x (TCO + TPX) rows x BK bf16, 16-B slots XOR-swizzled inside each 256-B bank row
-//         (conflict-free ds_read_b128 for the 32x32x16 operand maps); the swizzle is applied on the
-//         per-lane SOURCE address because an LDS-DMA writes lane-linear
+//   LDS   NST-stage ring x (TCO + TPX) rows x BK bf16, 16-B slots XOR-swizzled inside each 256-B bank
+//         row (conflict-free ds_read_b128 for the 32x32x16 operand maps); the swizzle is applied on the
+//         per-lane SOURCE address because an LDS-DMA writes lane-linear.  Loads run NST-1 stages ahead
+//         and stay in flight ACROSS the per-step barrier (counted s_waitcnt vmcnt(N) + raw s_barrier).
 //   MFMA  v_mfma_f32_32x32x16_bf16, A = weights (rows = co), B = activations (cols = px); each
-//         wave owns (TCO/2) x (TPX/2)
+//         wave owns (TCO/WCO) x (TPX/WPX)
+//   configs: 128x128 / 64x128 / 128x64 / 64x64 tiles with 4 waves and 2 stages (2 workgroups per CU),
+//         256x128 with 8 waves and 3 stages (1 workgroup per CU, 85 flop/B from L2) for the big layers
 //   epilogue  accumulators -> LDS fp32 [px][co] -> bias / LeakyReLU / dLeakyReLU -> 16-B coalesced
 //         bf16 stores along the channel axis (full 128/256-B lines per pixel)
 //   split-K over blockIdx.y with fp32 atomics (Linear layers: M = batch is tiny, K = 50176)
@@ -67,26 +70,37 @@ __device__ __forceinline__ int lds_off(int r, int chunk)
     return R * 256 + ((s ^ (R & 15)) << 4);
 }
 
-template <int TCO, int TPX, int BK>
+template <int N>
+__device__ __forceinline__ void wait_vmcnt()
+{
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <int TCO, int TPX, int BK, int WCO, int WPX, int NST>
 struct IgemmCfg {
+    static constexpr int NW = WCO * WPX;                     // waves per workgroup
+    static constexpr int NTHR = NW * 64;
     static constexpr int A_BYTES = TCO * BK * 2;
     static constexpr int B_BYTES = TPX * BK * 2;
     static constexpr int STAGE_BYTES = A_BYTES + B_BYTES;
     static constexpr int EP = TCO + 4;                       // fp32 epilogue row pitch (floats)
     static constexpr int EPI_BYTES = TPX * EP * 4;
     static constexpr int TABLE_BYTES = TPX * 32;             // per pixel: in_base, out_base, aux_base (int64 each, padded to 4)
-    static constexpr int MAIN_BYTES = (2 * STAGE_BYTES > EPI_BYTES) ? 2 * STAGE_BYTES : EPI_BYTES;
+    static constexpr int MAIN_BYTES = (NST * STAGE_BYTES > EPI_BYTES) ? NST * STAGE_BYTES : EPI_BYTES;
     static constexpr int LDS_BYTES = TABLE_BYTES + MAIN_BYTES;
-    static constexpr int A_INSTR = A_BYTES / 1024 / 4;       // glds wave-instructions per wave per stage
-    static constexpr int B_INSTR = B_BYTES / 1024 / 4;
-    static constexpr int MT = TCO / 64, NT = TPX / 64;       // 32x32 MFMA tiles per wave
+    static constexpr int A_INSTR = A_BYTES / 1024 / NW;      // glds wave-instructions per wave per stage
+    static constexpr int B_INSTR = B_BYTES / 1024 / NW;
+    static constexpr int LOADS = A_INSTR + B_INSTR;
+    static constexpr int MT = TCO / WCO / 32, NT = TPX / WPX / 32;  // 32x32 MFMA tiles per wave
+    static_assert(A_BYTES % (1024 * NW) == 0 && B_BYTES % (1024 * NW) == 0, "stage must split evenly over the waves");
+    static_assert(TPX <= NTHR, "one table entry per thread");
 };
 
-template <int TCO, int TPX, int BK>
-__global__ void __launch_bounds__(256, 2) igemm_kernel(const IgemmParams p)
+template <int TCO, int TPX, int BK, int WCO, int WPX, int NST>
+__global__ void __launch_bounds__(WCO * WPX * 64, (WCO * WPX == 4) ? 2 : 2) igemm_kernel(const IgemmParams p)
 {
-    using Cfg = IgemmCfg<TCO, TPX, BK>;
-    constexpr int MT = Cfg::MT, NT = Cfg::NT;
+    using Cfg = IgemmCfg<TCO, TPX, BK, WCO, WPX, NST>;
+    constexpr int MT = Cfg::MT, NT = Cfg::NT, NW = Cfg::NW, NTHR = Cfg::NTHR;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     long *tab = reinterpret_cast<long *>(smem);
     char *stage_base = smem + Cfg::TABLE_BYTES;
@@ -94,7 +108,7 @@ __global__ void __launch_bounds__(256, 2) igemm_kernel(const IgemmParams p)
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wco = wave >> 1, wpx = wave & 1;
+    const int wco = wave / WPX, wpx = wave % WPX;
 
     // ---- XCD-aware tile mapping: blocks b, b+8, b+16.. share an XCD; give each XCD a contiguous
     // range of logical tiles (co-tile fastest) so its private L2 sees one activation tile being
@@ -131,7 +145,7 @@ __global__ void __launch_bounds__(256, 2) igemm_kernel(const IgemmParams p)
         constexpr int CPR = BK / 8, RPB = 16 / CPR;
 #pragma unroll
         for (int i = 0; i < Cfg::A_INSTR; ++i) {
-            const int q = i * 4 + wave;             // wave-instruction index inside the A tile
+            const int q = i * NW + wave;            // wave-instruction index inside the A tile
             const int pos = q * 64 + lane;          // 16-B slot written by this lane
             const int R = pos >> 4, s = (pos & 15) ^ (R & 15);
             const int r = R * RPB + s / CPR, chunk = s % CPR;
@@ -142,7 +156,7 @@ __global__ void __launch_bounds__(256, 2) igemm_kernel(const IgemmParams p)
         }
 #pragma unroll
         for (int i = 0; i < Cfg::B_INSTR; ++i) {
-            const int q = i * 4 + wave;
+            const int q = i * NW + wave;
             const int pos = q * 64 + lane;
             const int R = pos >> 4, s = (pos & 15) ^ (R & 15);
             const int r = R * RPB + s / CPR, chunk = s % CPR;
@@ -177,9 +191,9 @@ __global__ void __launch_bounds__(256, 2) igemm_kernel(const IgemmParams p)
     // ---- fragment read offsets: lane l reads row (l&31), k-half (l>>5) of each 16-deep k-step
     int a_rd[MT], b_rd[NT];
 #pragma unroll
-    for (int i = 0; i < MT; ++i) a_rd[i] = lds_off<BK>(wco * (TCO / 2) + i * 32 + (lane & 31), lane >> 5);
+    for (int i = 0; i < MT; ++i) a_rd[i] = lds_off<BK>(wco * (TCO / WCO) + i * 32 + (lane & 31), lane >> 5);
 #pragma unroll
-    for (int i = 0; i < NT; ++i) b_rd[i] = Cfg::A_BYTES + lds_off<BK>(wpx * (TPX / 2) + i * 32 + (lane & 31), lane >> 5);
+    for (int i = 0; i < NT; ++i) b_rd[i] = Cfg::A_BYTES + lds_off<BK>(wpx * (TPX / WPX) + i * 32 + (lane & 31), lane >> 5);
 
     f32x16 acc[MT][NT];
 #pragma unroll
@@ -189,13 +203,22 @@ __global__ void __launch_bounds__(256, 2) igemm_kernel(const IgemmParams p)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-    if (kbeg < kend) stage(0, kbeg);
+    // ---- K loop: NST-stage ring, loads NST-1 steps ahead.  The LDS-DMA of later stages stays in
+    // flight across the barrier: each wave waits only for ITS loads of the stage about to be read
+    // (counted vmcnt), then the raw barrier makes every wave's part of that stage visible and proves
+    // that everyone has finished reading the stage that is overwritten next.
+    constexpr int D = NST - 1;
+#pragma unroll
+    for (int s0 = 0; s0 < D; ++s0)
+        if (kbeg + s0 < kend) stage(s0, kbeg + s0);
+    int cur = 0, nxt = D % NST;
     for (int it = kbeg; it < kend; ++it) {
-        const int buf = (it - kbeg) & 1;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();  // tile `it` has landed for every wave; buffer buf^1 is free again
-        if (it + 1 < kend) stage(buf ^ 1, it + 1);
-        const char *sb = stage_base + buf * Cfg::STAGE_BYTES;
+        if (D >= 2 && it + 1 < kend) wait_vmcnt<(D >= 2 ? (D - 1) * Cfg::LOADS : 0)>();
+        else wait_vmcnt<0>();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (it + D < kend) stage(nxt, it + D);
+        const char *sb = stage_base + cur * Cfg::STAGE_BYTES;
 #pragma unroll
         for (int ks = 0; ks < BK / 16; ++ks) {
             bf16x8 af[MT], bfr[NT];
@@ -209,6 +232,8 @@ __global__ void __launch_bounds__(256, 2) igemm_kernel(const IgemmParams p)
 #pragma unroll
                 for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
         }
+        cur = (cur + 1 == NST) ? 0 : cur + 1;
+        nxt = (nxt + 1 == NST) ? 0 : nxt + 1;
     }
     __syncthreads();  // all MFMA operand reads done before the stage area is reused for the epilogue
 
@@ -219,8 +244,8 @@ __global__ void __launch_bounds__(256, 2) igemm_kernel(const IgemmParams p)
     for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
-            const int px = wpx * (TPX / 2) + j * 32 + (lane & 31);
-            const int cob = wco * (TCO / 2) + i * 32 + 4 * (lane >> 5);
+            const int px = wpx * (TPX / WPX) + j * 32 + (lane & 31);
+            const int cob = wco * (TCO / WCO) + i * 32 + 4 * (lane >> 5);
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 f32x4 v = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
@@ -231,7 +256,7 @@ __global__ void __launch_bounds__(256, 2) igemm_kernel(const IgemmParams p)
 
     // ---- epilogue 2: coalesced along channels, 8 channels per thread per step
     constexpr int CCH = TCO / 8;            // 8-channel chunks per pixel
-    constexpr int PX_PER_STEP = 256 / CCH;  // pixels covered by the workgroup per step
+    constexpr int PX_PER_STEP = NTHR / CCH;  // pixels covered by the workgroup per step
     const int cc = tid % CCH;
     const int co = co0 + cc * 8;
     float bias8[8];
@@ -289,13 +314,13 @@ __global__ void __launch_bounds__(256, 2) igemm_kernel(const IgemmParams p)
     }
 }
 
-template <int TCO, int TPX, int BK>
+template <int TCO, int TPX, int BK, int WCO, int WPX, int NST>
 static int launch(const IgemmParams &p, int splits, hipStream_t s)
 {
-    using Cfg = IgemmCfg<TCO, TPX, BK>;
+    using Cfg = IgemmCfg<TCO, TPX, BK, WCO, WPX, NST>;
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&igemm_kernel<TCO, TPX, BK>), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&igemm_kernel<TCO, TPX, BK, WCO, WPX, NST>), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
         if (e != hipSuccess) return fail((int)e, "yolo_igemm: hipFuncSetAttribute(%d B LDS): %s", Cfg::LDS_BYTES, hipGetErrorString(e));
         attr_done = true;
     }
@@ -305,7 +330,7 @@ static int launch(const IgemmParams &p, int splits, hipStream_t s)
     q.nk = (int)(p.Ktot / BK);
     q.nk_per_split = (q.nk + splits - 1) / splits;
     const int real_splits = (q.nk + q.nk_per_split - 1) / q.nk_per_split;
-    hipLaunchKernelGGL((igemm_kernel<TCO, TPX, BK>), dim3(q.n_co_tiles * q.n_px_tiles, real_splits), dim3(256), Cfg::LDS_BYTES, s, q);
+    hipLaunchKernelGGL((igemm_kernel<TCO, TPX, BK, WCO, WPX, NST>), dim3(q.n_co_tiles * q.n_px_tiles, real_splits), dim3(Cfg::NTHR), Cfg::LDS_BYTES, s, q);
     return check_launch("yolo_igemm");
 }
 
@@ -340,13 +365,22 @@ YOLO_API int yolo_igemm(const yolo_igemm_desc *d, const void *in, const void *w,
     hipStream_t s = STRM(stream);
 
     const bool bk64 = (d->tap_len % 64) == 0;
-    const bool small_px = p.M <= 64;
     const bool small_co = d->Cout <= 64 || (d->Cout % 128 != 0 && d->Cout % 64 == 0 && d->Cout < 512);
+    const long tiles128 = ((p.M + 127) / 128) * ((d->Cout + 127) / 128);
+    const int force = d->tile_hint;   // 0 = heuristic; tests / tuning may force a configuration
     if (!bk64) {
-        if (small_co) return launch<64, 128, 32>(p, splits, s);
-        return launch<128, 128, 32>(p, splits, s);
+        if (small_co) return launch<64, 128, 32, 2, 2, 2>(p, splits, s);
+        return launch<128, 128, 32, 2, 2, 2>(p, splits, s);
     }
-    if (small_px) return small_co ? launch<64, 64, 64>(p, splits, s) : launch<128, 64, 64>(p, splits, s);
-    if (small_co) return launch<64, 128, 64>(p, splits, s);
-    return launch<128, 128, 64>(p, splits, s);
+    if (force == 1) return launch<128, 128, 64, 2, 2, 2>(p, splits, s);
+    if (force == 2) return launch<256, 128, 64, 4, 2, 3>(p, splits, s);
+    if (force == 3) return launch<128, 64, 64, 2, 2, 2>(p, splits, s);
+    if (force == 4) return launch<64, 128, 64, 2, 2, 2>(p, splits, s);
+    if (p.M <= 64) return small_co ? launch<64, 64, 64, 2, 2, 2>(p, splits, s) : launch<128, 64, 64, 2, 2, 2>(p, splits, s);
+    if (small_co) return launch<64, 128, 64, 2, 2, 2>(p, splits, s);
+    // big layers: 256x128 tiles (one 8-wave workgroup per CU, 3-stage ring) once they fill the chip
+    if (d->Cout % 256 == 0 && tiles128 >= 1024 && p.Ktot >= 1024) return launch<256, 128, 64, 4, 2, 3>(p, splits, s);
+    // few tiles (7x7 layers): halve the pixel tile to double the number of workgroups
+    if (tiles128 * splits < 320 && d->Cout >= 128) return launch<128, 64, 64, 2, 2, 2>(p, splits, s);
+    return launch<128, 128, 64, 2, 2, 2>(p, splits, s);
 }

@@ -1,0 +1,53 @@
+#!/usr/bin/env python3
+"""Run detection on image files (the reference's src/predict.py surface + an additive --backbone flag).
+
+    python yolo-v1_amd/predict.py image.jpg --checkpoint checkpoints/yolo_best.pth --device cuda --backbone yolov1
+"""
+
+from __future__ import annotations
+
+import argparse
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+import torch  # noqa: E402
+
+from yolo import YOLOv1, ResNetBackbone, YOLOv1Backbone  # noqa: E402
+from yolo.inference import YOLOInference  # noqa: E402
+from yolo.utils import VOC_CLASSES, draw_detections  # noqa: E402
+
+
+def load_model(checkpoint_path: str | None, device: str, num_classes: int = 20, backbone: str = "resnet50") -> YOLOv1:
+    bb = YOLOv1Backbone() if backbone == "yolov1" else ResNetBackbone(pretrained=False)
+    model = YOLOv1(backbone=bb, num_classes=num_classes)
+    if checkpoint_path:
+        ck = torch.load(checkpoint_path, map_location=device, weights_only=True)
+        model.load_state_dict(ck["model_state_dict"])
+    return model.eval().to(device)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("images", nargs="+")
+    ap.add_argument("--checkpoint", default=None)
+    ap.add_argument("--device", default="cuda" if torch.cuda.is_available() else "cpu")
+    ap.add_argument("--backbone", choices=["resnet50", "yolov1"], default="resnet50")
+    ap.add_argument("--conf-threshold", type=float, default=0.5)
+    ap.add_argument("--nms-threshold", type=float, default=0.4)
+    ap.add_argument("--output-dir", default=None)
+    a = ap.parse_args()
+    engine = YOLOInference(load_model(a.checkpoint, a.device, backbone=a.backbone), device=a.device)
+    for path in a.images:
+        dets = engine.predict(path, conf_threshold=a.conf_threshold, nms_threshold=a.nms_threshold, class_names=VOC_CLASSES)
+        print(f"{path}: {len(dets)} detections")
+        for d in dets:
+            print(f"  {d.class_name:12s} {d.confidence:.3f} {d.bbox}")
+        if a.output_dir:
+            os.makedirs(a.output_dir, exist_ok=True)
+            draw_detections(engine.load_image(path), dets).save(os.path.join(a.output_dir, os.path.basename(path)))
+
+
+if __name__ == "__main__":
+    main()

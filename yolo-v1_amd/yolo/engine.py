@@ -34,6 +34,8 @@ def _round_up(a: int, b: int) -> int:
 # bench.py / profiling: when TIMERS is a list, every MFMA / pool launch is bracketed by events on the
 # launch stream and (tag, kernel, flops, e0, e1) is appended.  None (default) = no events at all.
 TIMERS: list | None = None
+# tests / tuning: force a tile configuration of yolo_igemm (0 = library heuristic, see yolo_igemm_desc.tile_hint)
+TILE_HINT = 0
 
 
 class _timed:
@@ -261,6 +263,7 @@ class Plan:
         d.slope = self.SLOPE
         d.out_fp32 = 0
         d.split_k = 1
+        d.tile_hint = TILE_HINT
         return d
 
     # ------------------------------------------------------------------ forward
@@ -521,6 +524,7 @@ class Plan:
                 d.in_off = g.interior_off(L.K - 1 - L.pad)
                 d.stride, d.KH, d.KW, d.tap_len, d.Cout = 1, L.K, L.K, L.Cout, L.Cin
                 d.slope, d.out_fp32, d.split_k = self.SLOPE, 0, 1
+                d.tile_hint = TILE_HINT
                 if prev.kind == "conv":
                     gp = self._grad_buf(ws, li - 1, N, dev)
                     d.out_img_stride, d.out_row_stride, d.out_px_stride, d.out_off = self._grad_out_strides(prev, gp)
