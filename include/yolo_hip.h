@@ -130,8 +130,10 @@ typedef struct yolo_igemm_desc {
     /* aux addressing for YOLO_EPI_MUL_DLRELU (same form as the output addressing) */
     int64_t aux_img_stride;
     int32_t aux_row_stride, aux_px_stride, aux_off;
+    int32_t w_blocked;      /* 1: w is in the panel layout of yolo_pack_fc_weight_blocked (Linear layers)      */
     int32_t tile_hint;      /* 0 = let the library pick the tile configuration; 1: 128x128, 2: 256x128
-                               (8 waves, 3 stages), 3: 128x64, 4: 64x128  (tuning / tests)             */
+                               (8 waves, 3 stages), 3: 128x64, 4: 64x128, 5/6: 1/2 on the 16x16x32
+                               MFMA shape  (tuning / tests)                                        */
 } yolo_igemm_desc;
 
 #define YOLO_EPI_NONE 0        /* out = acc                                                        */
@@ -198,6 +200,10 @@ int yolo_pack_conv_weight(const float *w_oihw, int Cout, int Cin, int KH, int KW
 /* Linear weight [O][K] fp32 -> bf16 [O][K'] with the K axis permuted from (c, hw) to (hw, c) order
  * (HW = 1: plain cast) and, if wt != NULL, the transposed copy [K'][O] for the data-gradient. */
 int yolo_pack_fc_weight(const float *w, int O, int C, int HW, void *w_fwd_bf16, void *w_t_bf16, yolo_stream_t stream);
+/* Linear weight [O][K] fp32 (K % 64 == 0) -> bf16 panels [ceil(O/128)][K/64][128][64], rows >= O zero.
+ * With yolo_igemm_desc.w_blocked = 1 each LDS stage of the weight stream is one contiguous 16-KB read
+ * (a Linear layer at batch 64 is HBM-bound on its 822 MB / 411 MB weight). */
+int yolo_pack_fc_weight_blocked(const float *w, int O, long K, void *w_panels_bf16, yolo_stream_t stream);
 /* packed fp32 gradient [Cout][KH][KWp][Cinp] -> OIHW fp32 (accumulate=0: overwrite, 1: add). */
 int yolo_unpack_conv_wgrad(const float *dw_packed, int Cout, int Cin, int KH, int KW, int Cinp, int KWp,
                            float *dw_oihw, int accumulate, yolo_stream_t stream);

@@ -130,6 +130,31 @@ __global__ void __launch_bounds__(256) pack_fc_kernel(const float *__restrict__ 
     }
 }
 
+// w[o][k] fp32 -> bf16 panels [o/128][k/64][128][64] (rows >= O zero): every LDS stage of yolo_igemm then reads
+// one contiguous 16-KB run of a Linear layer's weight stream instead of 128 rows that lie K*2 bytes apart
+__global__ void pack_fc_blocked_kernel(const float *__restrict__ w, int O, long K, bf16_t *__restrict__ wb)
+{
+    const long nk = K / 64;
+    const long total8 = (long)((O + 127) / 128) * nk * 128 * 8;  // 8-element groups
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total8) return;
+    const int c8 = (int)(idx & 7);
+    const int r = (int)((idx >> 3) & 127);
+    const long kt = (idx >> 10) % nk;
+    const long ct = (idx >> 10) / nk;
+    const long o = ct * 128 + r;
+    uint4 out = {0u, 0u, 0u, 0u};
+    if (o < O) {
+        const float *src = w + o * K + kt * 64 + c8 * 8;
+        const float4 a = *reinterpret_cast<const float4 *>(src), b = *reinterpret_cast<const float4 *>(src + 4);
+        out.x = (unsigned)f32_to_bf16(a.x) | ((unsigned)f32_to_bf16(a.y) << 16);
+        out.y = (unsigned)f32_to_bf16(a.z) | ((unsigned)f32_to_bf16(a.w) << 16);
+        out.z = (unsigned)f32_to_bf16(b.x) | ((unsigned)f32_to_bf16(b.y) << 16);
+        out.w = (unsigned)f32_to_bf16(b.z) | ((unsigned)f32_to_bf16(b.w) << 16);
+    }
+    *reinterpret_cast<uint4 *>(wb + idx * 8) = out;
+}
+
 // generic tiled transposes: [R][Cc] -> [Cc][R]
 template <typename TI, typename TO, typename CV>
 __device__ __forceinline__ void transpose_tile(const TI *__restrict__ x, long R, long Cc, TO *__restrict__ y, long ld, CV cv)
@@ -363,4 +388,12 @@ YOLO_API int yolo_im2col_rows(const void *x, long x_img_stride, int x_row_stride
     hipLaunchKernelGGL(im2col_rows_kernel, dim3(nblk(total, 256)), dim3(256), 0, STRM(stream), (const bf16_t *)x, x_img_stride, x_row_stride, x_px_stride, stride, KH, seg,
                        N, Ho, Wo, out_halo, (bf16_t *)xcol);
     return check_launch("yolo_im2col_rows");
+}
+
+YOLO_API int yolo_pack_fc_weight_blocked(const float *w, int O, long K, void *wb, yolo_stream_t stream)
+{
+    if (!w || !wb || O <= 0 || K <= 0 || (K & 63)) return fail(YOLO_E_ARG, "yolo_pack_fc_weight_blocked: bad argument (K must be a multiple of 64)");
+    const long total8 = (long)((O + 127) / 128) * (K / 64) * 128 * 8;
+    hipLaunchKernelGGL(pack_fc_blocked_kernel, dim3(nblk(total8, 256)), dim3(256), 0, STRM(stream), w, O, K, (bf16_t *)wb);
+    return check_launch("yolo_pack_fc_weight_blocked");
 }

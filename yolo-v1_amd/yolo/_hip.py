@@ -33,6 +33,7 @@ class IgemmDesc(ctypes.Structure):
         ("epilogue", ctypes.c_int32), ("slope", ctypes.c_float), ("out_fp32", ctypes.c_int32), ("split_k", ctypes.c_int32),
         ("aux_img_stride", ctypes.c_int64),
         ("aux_row_stride", ctypes.c_int32), ("aux_px_stride", ctypes.c_int32), ("aux_off", ctypes.c_int32),
+        ("w_blocked", ctypes.c_int32),
         ("tile_hint", ctypes.c_int32),
     ]
 
@@ -80,6 +81,7 @@ _SIGS = {
     "yolo_dropout_bf16": [c_void_p, c_void_p, c_float, c_long, c_void_p, c_void_p],
     "yolo_pack_conv_weight": [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p],
     "yolo_pack_fc_weight": [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p],
+    "yolo_pack_fc_weight_blocked": [c_void_p, c_int, c_long, c_void_p, c_void_p],
     "yolo_unpack_conv_wgrad": [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p],
     "yolo_im2col_rows": [c_void_p, c_long, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p],
     "yolo_transpose_f32_to_bf16": [c_void_p, c_int, c_int, c_void_p, c_int, c_void_p],

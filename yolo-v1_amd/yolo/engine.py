@@ -165,6 +165,8 @@ class Plan:
                 layers.append(Layer("flatten"))
                 i += 1
             elif isinstance(m, nn.Linear):
+                if m.in_features % 64 or m.bias is None:
+                    raise ValueError(f"unsupported Linear {m}: in_features must be a multiple of 64")
                 act = isinstance(nxt, nn.LeakyReLU)
                 j = i + (2 if act else 1)
                 drop = 0.0
@@ -200,8 +202,9 @@ class Plan:
                     wd = torch.empty((L.Cin, L.K, L.K, L.Cout), dtype=torch.bfloat16, device=dev)
                 check(lib().yolo_pack_conv_weight(ptr(wsrc), L.Cout, L.Cin, L.K, L.K, L.Cin, L.K, ptr(wf), ptr(wd), stream()), "pack_conv_weight")
         else:
-            wf = torch.empty((L.Cout, L.Cin), dtype=torch.bfloat16, device=dev)
-            check(lib().yolo_cast_f32_to_bf16(ptr(wsrc), wsrc.numel(), ptr(wf), stream()), "cast")
+            # forward operand in 128x64 panels: contiguous 16-KB stage reads of the weight stream
+            wf = torch.empty((_round_up(L.Cout, 128) * L.Cin,), dtype=torch.bfloat16, device=dev)
+            check(lib().yolo_pack_fc_weight_blocked(ptr(wsrc), L.Cout, L.Cin, ptr(wf), stream()), "pack_fc_blocked")
             if need_dgrad:
                 ld = _round_up(L.Cout, 32)
                 wd = torch.zeros((L.Cin, ld), dtype=torch.bfloat16, device=dev)
@@ -314,6 +317,7 @@ class Plan:
                 d.out_img_stride, d.out_row_stride, d.out_px_stride, d.out_off = L.Cout, 0, L.Cout, 0
                 d.slope = self.SLOPE
                 d.out_fp32 = 1
+                d.w_blocked = 1
                 last = (li == len(self.layers) - 1)
                 nk = K // 64
                 splits = max(1, min(32, nk // 16)) if K >= 4096 else 1
