@@ -130,6 +130,8 @@ typedef struct yolo_igemm_desc {
     /* aux addressing for YOLO_EPI_MUL_DLRELU (same form as the output addressing) */
     int64_t aux_img_stride;
     int32_t aux_row_stride, aux_px_stride, aux_off;
+    int32_t pool2;          /* 1: fuse MaxPool2d(2,2) into the epilogue (conv -> LeakyReLU -> pool, models.py:49-55):
+                               Ho/Wo stay the CONV output size, out_* address the pooled map [Ho/2][Wo/2]     */
     int32_t w_blocked;      /* 1: w is in the panel layout of yolo_pack_fc_weight_blocked (Linear layers)      */
     int32_t tile_hint;      /* 0 = let the library pick the tile configuration; 1: 128x128, 2: 256x128
                                (8 waves, 3 stages), 3: 128x64, 4: 64x128, 5/6: 1/2 on the 16x16x32

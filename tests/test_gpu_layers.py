@@ -230,3 +230,34 @@ def test_every_tile_configuration(hint):
     _close(yg, yc, 6.0, f"hint {hint} y")
     for i, (a, b) in enumerate(zip(gg, gc)):
         _close(a, b, 12.0, f"hint {hint} grad {i}", frac=0.01)
+
+
+def test_fused_pool_epilogue_equals_separate_pool():
+    """inference path: conv+LeakyReLU+MaxPool as one launch must equal conv, then pool (bit for bit:
+    max and the bf16 rounding commute because rounding is monotone)."""
+    from yolo import engine
+    torch.manual_seed(5)
+    mods = nn.Sequential(nn.Conv2d(64, 192, 3, 1, 1), nn.LeakyReLU(0.1), nn.MaxPool2d(2, 2),
+                         nn.Conv2d(192, 64, 1), nn.LeakyReLU(0.1)).cuda().eval()
+    plan = engine.Plan.from_modules(list(mods), 64, False)
+    x = torch.randn(2, 64, 16, 32, device="cuda")
+    with torch.no_grad():
+        y_fused = engine.run_plan(plan, x, False)
+        engine.FUSE_POOL = False
+        try:
+            y_sep = engine.run_plan(plan, x, False)
+        finally:
+            engine.FUSE_POOL = True
+    assert torch.equal(y_fused, y_sep)
+    # and the 7x7/s2 stem followed by its pool (BK=32 configuration)
+    stem = nn.Sequential(nn.Conv2d(3, 64, 7, 2, 3), nn.LeakyReLU(0.1), nn.MaxPool2d(2, 2)).cuda().eval()
+    plan = engine.Plan.from_modules(list(stem), 3, True)
+    x = torch.randn(2, 3, 64, 64, device="cuda")
+    with torch.no_grad():
+        a = engine.run_plan(plan, x, False)
+        engine.FUSE_POOL = False
+        try:
+            b = engine.run_plan(plan, x, False)
+        finally:
+            engine.FUSE_POOL = True
+    assert torch.equal(a, b)

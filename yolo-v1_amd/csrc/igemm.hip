@@ -54,6 +54,7 @@ struct IgemmParams {
     int epilogue;
     float slope;
     int out_fp32;
+    int pool, pool_tw, pool_tiles_x, pool_tiles_y;   // fused MaxPool2d(2,2): pixel tiles are (TPX/pool_tw) x pool_tw patches
     int w_blocked;          // weights stored as [co_tile][k_iter][128][64] panels (Linear layers: contiguous 16-KB stage reads)
     int nk;                 // K iterations in total
     int nk_per_split;
@@ -131,16 +132,34 @@ __global__ void __launch_bounds__(WCO * WPX * 64, 2) igemm_kernel(const IgemmPar
     const int co0 = co_tile * TCO;
     const long px0 = (long)px_tile * TPX;
 
-    // ---- per-pixel address tables (input row base / output base), one pixel per thread
+    // ---- per-pixel address tables (input row base / output base), one pixel per thread.
+    // Normal mode: tile = TPX consecutive pixels of the flattened (n, oy, ox) index.
+    // Pool mode:   tile = a (TPX/TW) x TW patch of one image, so that every 2x2 pooling window lies
+    //              inside one tile; out_base then addresses the POOLED map.
     if (tid < TPX) {
-        long m = px0 + tid;
-        const bool valid = m < p.M;
-        if (!valid) m = p.M - 1;
-        const int n = (int)(m / p.HoWo);
-        const int rem = (int)(m - (long)n * p.HoWo);
-        const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+        int n, oy, ox;
+        bool valid;
+        if (p.pool) {
+            const int per_img = p.pool_tiles_x * p.pool_tiles_y;
+            n = px_tile / per_img;
+            const int t = px_tile - n * per_img;
+            const int ty = t / p.pool_tiles_x, tx = t - ty * p.pool_tiles_x;
+            oy = ty * (TPX / p.pool_tw) + tid / p.pool_tw;
+            ox = tx * p.pool_tw + tid % p.pool_tw;
+            valid = oy < p.HoWo / p.Wo && ox < p.Wo;
+            if (!valid) { oy = 0; ox = 0; }
+        } else {
+            long m = px0 + tid;
+            valid = m < p.M;
+            if (!valid) m = p.M - 1;
+            n = (int)(m / p.HoWo);
+            const int rem = (int)(m - (long)n * p.HoWo);
+            oy = rem / p.Wo;
+            ox = rem - oy * p.Wo;
+        }
         tab[4 * tid] = (long)n * p.in_img_stride + (long)(oy * p.stride) * p.in_row_stride + (long)(ox * p.stride) * p.in_px_stride + p.in_off;
-        tab[4 * tid + 1] = valid ? ((long)n * p.out_img_stride + (long)oy * p.out_row_stride + (long)ox * p.out_px_stride + p.out_off) : -1;
+        const int qy = p.pool ? oy >> 1 : oy, qx = p.pool ? ox >> 1 : ox;
+        tab[4 * tid + 1] = valid ? ((long)n * p.out_img_stride + (long)qy * p.out_row_stride + (long)qx * p.out_px_stride + p.out_off) : -1;
         tab[4 * tid + 2] = (long)n * p.aux_img_stride + (long)oy * p.aux_row_stride + (long)ox * p.aux_px_stride + p.aux_off;
     }
     __syncthreads();
@@ -308,6 +327,31 @@ __global__ void __launch_bounds__(WCO * WPX * 64, 2) igemm_kernel(const IgemmPar
         }
         return;
     }
+    if (p.pool) {
+        // fused MaxPool2d(2,2): max over the window's four LDS rows, then bias + LeakyReLU (monotone, so
+        // pool(lrelu(z + b)) == lrelu(max(z) + b)); one 16-B store per pooled pixel and channel chunk
+        const int tw = p.pool_tw, hw = tw >> 1;
+        for (int q = tid / CCH; q < TPX / 4; q += PX_PER_STEP) {
+            const int l00 = (q / hw) * 2 * tw + (q % hw) * 2;
+            const long ob = tab[4 * l00 + 1];
+            if (ob < 0 || co >= p.Cout) continue;
+            float v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const float a = ep[l00 * Cfg::EP + cc * 8 + k], b = ep[(l00 + 1) * Cfg::EP + cc * 8 + k];
+                const float c = ep[(l00 + tw) * Cfg::EP + cc * 8 + k], d = ep[(l00 + tw + 1) * Cfg::EP + cc * 8 + k];
+                float m = fmaxf(fmaxf(a, b), fmaxf(c, d)) + bias8[k];
+                v[k] = (p.epilogue == YOLO_EPI_BIAS_LRELU && m < 0.0f) ? m * p.slope : m;
+            }
+            uint4 pk;
+            pk.x = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
+            pk.y = (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
+            pk.z = (unsigned)f32_to_bf16(v[4]) | ((unsigned)f32_to_bf16(v[5]) << 16);
+            pk.w = (unsigned)f32_to_bf16(v[6]) | ((unsigned)f32_to_bf16(v[7]) << 16);
+            *reinterpret_cast<uint4 *>(reinterpret_cast<bf16_t *>(p.out) + ob + co) = pk;
+        }
+        return;
+    }
 #pragma unroll 2
     for (int px = tid / CCH; px < TPX; px += PX_PER_STEP) {
         const long ob = tab[4 * px + 1];
@@ -367,7 +411,13 @@ static int launch(const IgemmParams &p, int splits, hipStream_t s)
     }
     IgemmParams q = p;
     q.n_co_tiles = (p.Cout + TCO - 1) / TCO;
-    q.n_px_tiles = (int)((p.M + TPX - 1) / TPX);
+    if (p.pool) {
+        q.pool_tiles_x = (p.Wo + p.pool_tw - 1) / p.pool_tw;
+        q.pool_tiles_y = (p.HoWo / p.Wo + TPX / p.pool_tw - 1) / (TPX / p.pool_tw);
+        q.n_px_tiles = (int)(p.M / p.HoWo) * q.pool_tiles_x * q.pool_tiles_y;
+    } else {
+        q.n_px_tiles = (int)((p.M + TPX - 1) / TPX);
+    }
     q.nk = (int)(p.Ktot / BK);
     q.nk_per_split = (q.nk + splits - 1) / splits;
     const int real_splits = (q.nk + q.nk_per_split - 1) / q.nk_per_split;
@@ -410,6 +460,10 @@ YOLO_API int yolo_igemm(const yolo_igemm_desc *d, const void *in, const void *w,
     const long tiles128 = ((p.M + 127) / 128) * ((d->Cout + 127) / 128);
     const int force = d->tile_hint;   // 0 = heuristic; tests / tuning may force a configuration
     p.w_blocked = d->w_blocked;
+    p.pool = d->pool2 ? 1 : 0;
+    p.pool_tw = 16;
+    if (p.pool && (splits > 1 || d->out_fp32 || (d->Ho & 1) || (d->Wo & 1) || (d->epilogue != YOLO_EPI_BIAS && d->epilogue != YOLO_EPI_BIAS_LRELU)))
+        return fail(YOLO_E_UNSUPPORTED, "yolo_igemm: pool2 needs even Ho/Wo, bf16 output, a bias epilogue and no split-K");
     if (d->w_blocked) {
         if (!bk64) return fail(YOLO_E_UNSUPPORTED, "yolo_igemm: blocked weights need tap_len %% 64 == 0");
         return p.M <= 64 ? launch<128, 64, 64, 2, 2, 2, MFMA_16x16x32>(p, splits, s) : launch<128, 128, 64, 2, 2, 2, MFMA_16x16x32>(p, splits, s);
@@ -417,6 +471,10 @@ YOLO_API int yolo_igemm(const yolo_igemm_desc *d, const void *in, const void *w,
     if (!bk64) {
         if (small_co) return launch<64, 128, 32, 2, 2, 2>(p, splits, s);
         return launch<128, 128, 32, 2, 2, 2>(p, splits, s);
+    }
+    if (p.pool) {   // pooled epilogue works on 8 x 16 pixel patches = 128-pixel tiles
+        if (small_co) return launch<64, 128, 64, 2, 2, 2, MFMA_16x16x32>(p, splits, s);
+        return launch<128, 128, 64, 2, 2, 2, MFMA_16x16x32>(p, splits, s);
     }
     if (force == 1) return launch<128, 128, 64, 2, 2, 2>(p, splits, s);
     if (force == 2) return launch<256, 128, 64, 4, 2, 3>(p, splits, s);

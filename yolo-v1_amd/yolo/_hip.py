@@ -33,6 +33,7 @@ class IgemmDesc(ctypes.Structure):
         ("epilogue", ctypes.c_int32), ("slope", ctypes.c_float), ("out_fp32", ctypes.c_int32), ("split_k", ctypes.c_int32),
         ("aux_img_stride", ctypes.c_int64),
         ("aux_row_stride", ctypes.c_int32), ("aux_px_stride", ctypes.c_int32), ("aux_off", ctypes.c_int32),
+        ("pool2", ctypes.c_int32),
         ("w_blocked", ctypes.c_int32),
         ("tile_hint", ctypes.c_int32),
     ]

@@ -36,6 +36,7 @@ def _round_up(a: int, b: int) -> int:
 TIMERS: list | None = None
 # tests / tuning: force a tile configuration of yolo_igemm (0 = library heuristic, see yolo_igemm_desc.tile_hint)
 TILE_HINT = 0
+FUSE_POOL = True   # inference: fold MaxPool2d(2,2) into the preceding conv's epilogue where the geometry allows
 
 
 class _timed:
@@ -289,15 +290,27 @@ class Plan:
         cur = a
         fc_saved = {}
         out = None
+        skip_pool = False
         for li, L in enumerate(self.layers):
             nxt = ws["acts"][li]
             if L.kind == "conv":
                 wf, _ = self._pack(li, train)
+                # inference: conv -> LeakyReLU -> MaxPool2d(2,2) as ONE launch when the conv output tiles into
+                # 8 x 16 pixel patches (the first two layers: 224^2 and 112^2); training keeps the un-pooled
+                # activation, which the backward pass needs
+                fuse = (not train and FUSE_POOL and li + 1 < len(self.layers) and self.layers[li + 1].kind == "pool"
+                        and L.Hout % 8 == 0 and L.Wout % 16 == 0 and L.Cout % 8 == 0)
+                if fuse:
+                    nxt = ws["acts"][li + 1]
                 d = self._conv_desc(L, cur, nxt)
+                d.pool2 = 1 if fuse else 0
                 b = L.bias.detach()
-                with _timed(f"conv{li}", "igemm", 2.0 * N * L.Hout * L.Wout * L.Cout * L.Cin * L.K * L.K):
+                with _timed(f"conv{li}" + ("+pool" if fuse else ""), "igemm", 2.0 * N * L.Hout * L.Wout * L.Cout * L.Cin * L.K * L.K):
                     check(L_.yolo_igemm(ctypes.byref(d), cur.p, ptr(wf), ptr(b), None, nxt.p, st), f"igemm conv{li}")
                 cur = nxt
+                skip_pool = fuse
+            elif L.kind == "pool" and skip_pool:
+                skip_pool = False
             elif L.kind == "pool":
                 pd = PoolDesc(N, cur.H, cur.W, cur.C, cur.halo, nxt.halo)
                 with _timed(f"pool{li}", "maxpool2_fwd"):
@@ -590,9 +603,8 @@ class PlanFunction(torch.autograd.Function):
     """autograd bridge: forward/backward of a whole plan as ONE node (no per-layer autograd graph)."""
 
     @staticmethod
-    def forward(ctx, plan: Plan, drop_training: bool, x: torch.Tensor, *params):
-        need = any(ctx.needs_input_grad)
-        out, saved = plan.forward(x, need, drop_training)
+    def forward(ctx, plan: Plan, drop_training: bool, need_grad: bool, x: torch.Tensor, *params):
+        out, saved = plan.forward(x, need_grad, drop_training)
         ctx.plan = plan
         ctx.saved = saved
         ctx.x_needs = x.requires_grad
@@ -604,9 +616,11 @@ class PlanFunction(torch.autograd.Function):
             raise RuntimeError("backward through a plan that ran without grad")
         gx, pg = ctx.plan.backward(ctx.saved, gout, ctx.x_needs)
         ctx.saved = None
-        return (None, None, gx, *pg)
+        return (None, None, None, gx, *pg)
 
 
 def run_plan(plan: Plan, x: torch.Tensor, drop_training: bool) -> torch.Tensor:
     _hip.require_cuda(x)
-    return PlanFunction.apply(plan, drop_training, x, *plan.params)
+    # grad mode must be sampled here: inside Function.forward it is always off
+    need = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in plan.params))
+    return PlanFunction.apply(plan, drop_training, need, x, *plan.params)
