@@ -39,7 +39,7 @@ HBM_PEAK_GBS = 8000.0
 
 def _sync_all(world):
     torch.cuda.synchronize()
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
     torch.cuda.synchronize()
 
@@ -54,7 +54,7 @@ def timed_steps(fn, steps, warmup, world):
         fn()
     _sync_all(world)
     dt = time.perf_counter() - t0
-    if world > 1:
+    if dist.is_initialized():
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -80,9 +80,10 @@ def main():
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    use_dist = "RANK" in os.environ and "MASTER_PORT" in os.environ     # launched by torch.distributed.run
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        dist.init_process_group("nccl", device_id=dev)                    # backend "nccl" = RCCL on ROCm
 
     import synth
     from yolo import YOLOLoss, YOLOv1, engine, ops
@@ -91,7 +92,7 @@ def main():
     B = a.batch
     torch.manual_seed(0)
     model = YOLOv1().to(dev)
-    if world > 1:
+    if use_dist:
         for p_ in model.parameters():
             dist.broadcast(p_.data, 0)
     # synthetic inputs, resident in HBM before any timed region
@@ -143,7 +144,7 @@ def main():
         crit = YOLOLoss()
         from yolo.optim import Adam
         opt = Adam(model.parameters(), lr=1e-4, weight_decay=5e-4, max_grad_norm=10.0)  # clip_grad_norm_(10) + Adam fused
-        ar = GradAllReduce(model.parameters()) if world > 1 else None
+        ar = GradAllReduce(model.parameters()) if use_dist else None
 
         def step():
             opt.zero_grad(set_to_none=True)
@@ -228,7 +229,7 @@ def main():
             "roofline": roof, "cpu_baseline": cpu, "train": train, "nms": nms,
         }
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

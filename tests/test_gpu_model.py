@@ -199,3 +199,28 @@ def test_hip_adam_matches_torch_adam():
         torch.testing.assert_close(p.grad, q.grad, rtol=1e-5, atol=1e-7)
     # state_dict is interchangeable with torch.optim.Adam
     ob.load_state_dict(oa.state_dict())
+
+
+def test_detection_head_on_the_engine():
+    """DetectionHead (conv 3x3 x4 incl. stride 2, Flatten, FC) forward + backward on the HIP plan vs the
+    bf16-faithful stock-torch reference (narrow input so that the CPU side stays cheap)."""
+    import copy
+    from test_gpu_layers import _bf, _close, bf16_faithful
+    from yolo import DetectionHead
+    torch.manual_seed(7)
+    head = DetectionHead(256, num_classes=20, S=7, B=2).eval()
+    x = torch.randn(2, 256, 14, 14)
+    gy = torch.randn(2, 7, 7, 30)
+    g = copy.deepcopy(head).cuda()
+    ref = torch.nn.Sequential(bf16_faithful(head.conv_layers), bf16_faithful(head.fc_layers))
+    xc = _bf(x).requires_grad_(True)
+    yc = ref(xc).view(-1, 7, 7, 30)
+    yc.backward(gy)
+    xg = x.clone().cuda().requires_grad_(True)
+    yg = g(xg)
+    assert yg.shape == (2, 7, 7, 30)
+    yg.backward(gy.cuda())
+    _close(yg, yc, 8.0, "head y")
+    _close(xg.grad, xc.grad, 16.0, "head gx", frac=0.02)
+    for (n, p1), (_, p2) in zip(g.named_parameters(), head.named_parameters()):
+        _close(p1.grad, p2.grad, 16.0, f"head {n}", frac=0.02)

@@ -20,16 +20,26 @@ for item in synth.YOLOV1_BACKBONE_CFG:
     idx, (co, ci, k, s, p) = item
     hin = h
     h = (h + 2 * p - k) // s + 1
-    if idx == 0:
+    only = os.environ.get("LAYERS")
+    if only and str(idx) not in only.split(","):
         continue
-    x = Act(N, hin, hin, ci, 1, dev); y = Act(N, h, h, co, 1, dev)
+    pool = int(os.environ.get("POOL", "0")) and idx in (0, 3)
+    if idx == 0:
+        x = Act(N, hin, hin, 4, 3, dev)
+    else:
+        x = Act(N, hin, hin, ci, 1, dev)
+    y = Act(N, h // 2, h // 2, co, 1, dev) if pool else Act(N, h, h, co, 1, dev)
     x.t.normal_()
-    w = torch.randn((co, k, k, ci), device=dev).to(torch.bfloat16)
+    w = torch.randn((co, 7, 8, 4) if idx == 0 else (co, k, k, ci), device=dev).to(torch.bfloat16)
     b = torch.randn((co,), device=dev)
     d = IgemmDesc()
     d.N, d.Ho, d.Wo = N, h, h
     d.in_img_stride, d.in_row_stride, d.in_px_stride = x.img_stride, x.row_stride, x.px_stride
-    d.in_off = x.interior_off(p); d.stride = s; d.KH = d.KW = k; d.tap_len = ci; d.Cout = co
+    d.stride = s; d.Cout = co; d.pool2 = 1 if pool else 0
+    if idx == 0:
+        d.in_off = 0; d.KH, d.KW, d.tap_len = 7, 1, 32
+    else:
+        d.in_off = x.interior_off(p); d.KH = d.KW = k; d.tap_len = ci
     d.out_img_stride, d.out_row_stride, d.out_px_stride, d.out_off = y.img_stride, y.row_stride, y.px_stride, y.interior_off()
     d.epilogue, d.slope, d.out_fp32, d.split_k = EPI_BIAS_LRELU, 0.1, 0, 1
     fl = 2.0 * N * h * h * co * ci * k * k

@@ -469,9 +469,13 @@ YOLO_API int yolo_igemm(const yolo_igemm_desc *d, const void *in, const void *w,
         return p.M <= 64 ? launch<128, 64, 64, 2, 2, 2, MFMA_16x16x32>(p, splits, s) : launch<128, 128, 64, 2, 2, 2, MFMA_16x16x32>(p, splits, s);
     }
     if (!bk64) {
-        if (small_co) return launch<64, 128, 32, 2, 2, 2>(p, splits, s);
+        if (force == 7) return launch<64, 128, 32, 2, 2, 3>(p, splits, s);
+        if (force == 9) return launch<64, 128, 32, 2, 2, 4>(p, splits, s);
+        if (force == 10) return launch<64, 128, 32, 2, 2, 2>(p, splits, s);
+        if (small_co) return launch<64, 128, 32, 2, 2, 3>(p, splits, s);
         return launch<128, 128, 32, 2, 2, 2>(p, splits, s);
     }
+    if (force == 8) return launch<64, 128, 64, 2, 2, 3, MFMA_16x16x32>(p, splits, s);
     if (p.pool) {   // pooled epilogue works on 8 x 16 pixel patches = 128-pixel tiles
         if (small_co) return launch<64, 128, 64, 2, 2, 2, MFMA_16x16x32>(p, splits, s);
         return launch<128, 128, 64, 2, 2, 2, MFMA_16x16x32>(p, splits, s);

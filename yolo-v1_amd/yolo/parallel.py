@@ -34,8 +34,6 @@ class GradAllReduce:
 
     def all_reduce_mean(self) -> None:
         world = dist.get_world_size(self.group)
-        if world == 1:
-            return
         grads = [p.grad for p in self.params if p.grad is not None]
         big = [g for g in grads if g.numel() * g.element_size() >= self.big_bytes]
         small = [g for g in grads if g.numel() * g.element_size() < self.big_bytes]
