@@ -129,10 +129,18 @@ def main():
         n_launch = sum(1 for v in agg.values() if v[0] == "igemm")
         layer_rows = [(k, v[0], v[1], v[2]) for k, v in agg.items()]
         ach = ig_fl / (ig_ms * 1e-3) / 1e12
-        roof = {"kernel": "igemm_kernel (implicit-GEMM conv/FC, v_mfma_f32_32x32x16_bf16)", "bound": "mfma",
+        # HBM bytes per launch from PMC counters: measured by tools/collect_traffic.sh (two separate
+        # rocprofv3 --pmc passes of this very command) and committed under profiles/ -- a bench run
+        # cannot profile itself
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "r1_igemm_traffic.json")
+        if os.path.exists(tpath):
+            traffic = round(json.load(open(tpath))["hbm_bytes_per_launch"])
+        roof = {"kernel": "igemm_kernel (implicit-GEMM conv/FC, v_mfma_f32_16x16x32_bf16)", "bound": "mfma",
                 "achieved": round(ach, 2), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4),
-                "traffic": None, "launches_per_step": n_launch, "avg_launch_ms": round(ig_ms / n_launch, 4),
-                "flops_per_step": ig_fl, "kernel_ms_per_step": round(ig_ms, 3)}
+                "traffic": traffic, "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/r1_igemm_traffic.json)",
+                "launches_per_step": n_launch, "avg_launch_ms": round(ig_ms / n_launch, 4),
+                "flops_per_launch": ig_fl / n_launch, "flops_per_step": ig_fl, "kernel_ms_per_step": round(ig_ms, 3)}
         if a.layers:
             for k, kern, fl, ms in layer_rows:
                 print(f"{k:14s} {kern:14s} {ms:8.3f} ms {fl / max(ms, 1e-9) / 1e9:9.1f} TFLOP/s", file=sys.stderr)

@@ -1,0 +1,27 @@
+#!/usr/bin/env python3
+"""Turn the two rocprofv3 --pmc passes of tools/collect_traffic.sh into per-launch HBM bytes of igemm_kernel.
+
+Units / corrections (MI355X_MICROARCH.md, section HBM): FETCH_SIZE and WRITE_SIZE are in KiB; on gfx950
+FETCH_SIZE reports exactly half of the bytes of a wide coalesced streaming read (16 B per lane, LDS-DMA
+included) -> doubled; WRITE_SIZE is exact for 16-B-per-lane stores."""
+import csv, json, sys, collections
+d = sys.argv[1]
+tot = {}
+n = {}
+for c in ("FETCH_SIZE", "WRITE_SIZE"):
+    s = 0.0
+    k = 0
+    for r in csv.DictReader(open(f"{d}/pmc_{c}_counter_collection.csv")):
+        if "igemm_kernel" in r["Kernel_Name"] and r["Counter_Name"] == c:
+            s += float(r["Counter_Value"])
+            k += 1
+    tot[c], n[c] = s, k
+launches = n["FETCH_SIZE"]
+fetch = 2.0 * tot["FETCH_SIZE"] * 1024
+write = tot["WRITE_SIZE"] * 1024
+print(json.dumps({
+    "kernel": "igemm_kernel", "launches_counted": launches,
+    "hbm_read_bytes_per_launch": fetch / launches, "hbm_write_bytes_per_launch": write / launches,
+    "hbm_bytes_per_launch": (fetch + write) / launches,
+    "correction": "FETCH_SIZE x2 (gfx950 half-count of wide coalesced reads), KiB -> bytes; WRITE_SIZE exact",
+    "command": "rocprofv3 --pmc <C> -- python3 bench.py --steps 3 --warmup 1 --no-train --no-nms --no-cpu (separate passes)"}))
