@@ -71,6 +71,7 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-nms", action="store_true")
     ap.add_argument("--layers", action="store_true", help="print the per-layer kernel table to stderr")
+    ap.add_argument("--resnet", action="store_true", help="also time BASELINE configs[4]: ResNet50 variant, batch 64 inference + NMS")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -197,6 +198,31 @@ def main():
         dtp = (time.perf_counter() - t0) / 200
         nms = {"value": round(64 * 98 / dtp, 1), "unit": "raw boxes/s", "us_per_batch64": round(dtp * 1e6, 1), "config": "64x(7,7,30)~U(0,1), conf 0.3, nms 0.4, metrics variant"}
 
+    # ---------------------------------------------------------------- ResNet50 variant (configs[4])
+    resnet = None
+    if a.resnet and rank == 0:
+        from yolo import ResNetBackbone
+        del model
+        torch.cuda.empty_cache()
+        rm = YOLOv1(backbone=ResNetBackbone(pretrained=False, freeze=True)).to(dev).eval()
+
+        def rfwd():
+            with torch.no_grad():
+                pr = rm(x)
+                rec, cnt = ops.decode(pr, 0.3, 7, 2, 20)
+                return ops.nms(rec, cnt, 0.4, 0)
+
+        for _ in range(3):
+            rfwd()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(10):
+            rfwd()
+        torch.cuda.synchronize()
+        dtr = (time.perf_counter() - t0) / 10
+        resnet = {"value": round(B / dtr, 1), "unit": "images/s", "ms_per_batch": round(dtr * 1e3, 3),
+                  "config": "configs[4]: YOLOv1(ResNetBackbone) batch 64 inference (BN folded) + decode + NMS conf 0.3 / nms 0.4, random init"}
+
     # ---------------------------------------------------------------- CPU baseline (rank 0, N=1 only)
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu:
@@ -234,7 +260,7 @@ def main():
             "config": {"workload": "BASELINE.json configs[1]: batch=64/GPU 448x448 forward-only, YOLOv1Backbone + FC head, 1xMI355X per rank",
                        "global_batch": world * B, "per_gpu_batch": B, "weights": "random init (torch default, seed 0)",
                        "flops_per_image": 40.57e9, "parallelism": f"dp{world}" if world > 1 else "single"},
-            "roofline": roof, "cpu_baseline": cpu, "train": train, "nms": nms,
+            "roofline": roof, "cpu_baseline": cpu, "train": train, "nms": nms, "resnet50_variant": resnet,
         }
         print(json.dumps(out))
     if use_dist:

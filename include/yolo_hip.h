@@ -145,6 +145,9 @@ typedef struct yolo_igemm_desc {
                                   previous layer's LeakyReLU; aux = that layer's output, bf16,
                                   addressed by the aux_* strides)                                                        */
 
+#define YOLO_EPI_BIAS_ADD_LRELU 4 /* out = lrelu(acc + bias[co] + aux[px][co])  (residual add of a ResNet bottleneck,
+                                    slope 0 = ReLU; aux = identity / downsample branch, bf16, aux_* strides)  */
+
 int yolo_igemm(const yolo_igemm_desc *d, const void *in_bf16, const void *w_bf16 /*[Cout][KH*KW*tap_len]*/,
                const float *bias, const void *aux_bf16, void *out, yolo_stream_t stream);
 
@@ -180,6 +183,9 @@ typedef struct yolo_pool_desc {
     int32_t N, H, W, C;       /* un-pooled logical size                                          */
     int32_t in_halo, out_halo;
 } yolo_pool_desc;
+/* MaxPool2d(3, stride 2, pad 1) forward (ResNet stem).  The input must be >= 0 (it follows a ReLU), so
+ * the zero halo of the buffer is equivalent to the -inf padding of the operator.  H, W = input size. */
+int yolo_maxpool3s2_fwd(const yolo_pool_desc *d, const void *x_bf16, void *y_bf16, yolo_stream_t stream);
 int yolo_maxpool2_fwd(const yolo_pool_desc *d, const void *x_bf16, void *y_bf16, yolo_stream_t stream);
 int yolo_maxpool2_bwd_lrelu(const yolo_pool_desc *d, const void *yfull_bf16, const void *dpool_bf16,
                             float slope, void *dz_bf16, yolo_stream_t stream);

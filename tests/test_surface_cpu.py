@@ -235,3 +235,21 @@ def test_cpu_loss_matches_reference_fixtures():
     t[0, 1, 1, 14] = 1.0
     with pytest.raises(RuntimeError):
         YOLOLoss()(torch.zeros(1, 7, 7, 30), t)
+
+
+# ---------------------------------------------------------------- ResNet50 variant (reference tests/test_backbone.py:57-86,116-126)
+def test_resnet_backbone_surface():
+    from yolo import ResNetBackbone
+    bb = ResNetBackbone(pretrained=False, freeze=True)
+    assert all(not p.requires_grad for p in bb.parameters())
+    assert all(p.requires_grad for p in ResNetBackbone(pretrained=False, freeze=False).parameters())
+    assert sum(p.numel() for p in bb.parameters()) == 23_508_032          # resnet50 minus its fc layer
+    keys = list(bb.state_dict().keys())
+    assert keys[0] == "extractor.0.weight" and "extractor.4.0.downsample.0.weight" in keys and "extractor.7.2.bn3.running_var" in keys
+    with torch.no_grad():
+        f = bb.eval()(torch.randn(1, 3, 448, 448))
+    assert f.shape == (1, 2048, 14, 14)
+    m = YOLOv1(backbone=bb)
+    assert isinstance(m.head, DetectionHead) and sum(p.numel() for p in m.head.parameters()) == 258_737_598
+    with pytest.raises(ImportError):
+        ResNetBackbone(pretrained=True)      # ImageNet weights need torchvision + a download

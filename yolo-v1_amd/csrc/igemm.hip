@@ -314,7 +314,7 @@ __global__ void __launch_bounds__(WCO * WPX * 64, 2) igemm_kernel(const IgemmPar
     const int co = co0 + cc * 8;
     float bias8[8];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) bias8[k] = (p.epilogue == YOLO_EPI_BIAS || p.epilogue == YOLO_EPI_BIAS_LRELU) && (co + k < p.Cout) ? p.bias[co + k] : 0.0f;
+    for (int k = 0; k < 8; ++k) bias8[k] = (p.epilogue == YOLO_EPI_BIAS || p.epilogue == YOLO_EPI_BIAS_LRELU || p.epilogue == YOLO_EPI_BIAS_ADD_LRELU) && (co + k < p.Cout) ? p.bias[co + k] : 0.0f;
     const bool split = gridDim.y > 1;
     if (split) {
         // split-K partial tile: fp32 atomics shaped as 256 contiguous bytes per wave-instruction (one
@@ -361,11 +361,20 @@ __global__ void __launch_bounds__(WCO * WPX * 64, 2) igemm_kernel(const IgemmPar
         const f32x4 hi = *reinterpret_cast<const f32x4 *>(ep + px * Cfg::EP + cc * 8 + 4);
         v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3];
         v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
-        if (p.epilogue == YOLO_EPI_BIAS || p.epilogue == YOLO_EPI_BIAS_LRELU) {
+        if (p.epilogue == YOLO_EPI_BIAS || p.epilogue == YOLO_EPI_BIAS_LRELU || p.epilogue == YOLO_EPI_BIAS_ADD_LRELU) {
 #pragma unroll
             for (int k = 0; k < 8; ++k) v[k] += bias8[k];
         }
-        if (p.epilogue == YOLO_EPI_BIAS_LRELU) {
+        if (p.epilogue == YOLO_EPI_BIAS_ADD_LRELU) {
+            // residual branch (ResNet bottleneck): out = act(conv + bias + identity)
+            const uint4 y = *reinterpret_cast<const uint4 *>(p.aux + tab[4 * px + 2] + co);
+            const unsigned yy[4] = {y.x, y.y, y.z, y.w};
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                v[k] += __uint_as_float((k & 1) ? (yy[k >> 1] & 0xffff0000u) : (yy[k >> 1] << 16));
+                v[k] = v[k] > 0.0f ? v[k] : v[k] * p.slope;
+            }
+        } else if (p.epilogue == YOLO_EPI_BIAS_LRELU) {
 #pragma unroll
             for (int k = 0; k < 8; ++k) v[k] = v[k] > 0.0f ? v[k] : v[k] * p.slope;
         } else if (p.epilogue == YOLO_EPI_MUL_DLRELU) {
@@ -434,9 +443,9 @@ YOLO_API int yolo_igemm(const yolo_igemm_desc *d, const void *in, const void *w,
     if (!d || !in || !w || !out) return fail(YOLO_E_ARG, "yolo_igemm: null pointer");
     if (d->N <= 0 || d->Ho <= 0 || d->Wo <= 0 || d->KH <= 0 || d->KW <= 0 || d->tap_len <= 0 || d->Cout <= 0 || d->stride <= 0)
         return fail(YOLO_E_ARG, "yolo_igemm: bad descriptor");
-    if ((d->epilogue == YOLO_EPI_BIAS || d->epilogue == YOLO_EPI_BIAS_LRELU) && !bias) return fail(YOLO_E_ARG, "yolo_igemm: epilogue needs bias");
-    if (d->epilogue == YOLO_EPI_MUL_DLRELU && !aux) return fail(YOLO_E_ARG, "yolo_igemm: epilogue needs aux");
-    if (d->epilogue < 0 || d->epilogue > YOLO_EPI_MUL_DLRELU) return fail(YOLO_E_ARG, "yolo_igemm: epilogue %d", d->epilogue);
+    if ((d->epilogue == YOLO_EPI_BIAS || d->epilogue == YOLO_EPI_BIAS_LRELU || d->epilogue == YOLO_EPI_BIAS_ADD_LRELU) && !bias) return fail(YOLO_E_ARG, "yolo_igemm: epilogue needs bias");
+    if ((d->epilogue == YOLO_EPI_MUL_DLRELU || d->epilogue == YOLO_EPI_BIAS_ADD_LRELU) && !aux) return fail(YOLO_E_ARG, "yolo_igemm: epilogue needs aux");
+    if (d->epilogue < 0 || d->epilogue > YOLO_EPI_BIAS_ADD_LRELU) return fail(YOLO_E_ARG, "yolo_igemm: epilogue %d", d->epilogue);
     const int splits = d->split_k > 1 ? d->split_k : 1;
     if (splits > 1 && (!d->out_fp32 || d->epilogue != YOLO_EPI_NONE)) return fail(YOLO_E_ARG, "yolo_igemm: split_k needs fp32 output and EPI_NONE");
     if (!d->out_fp32 && ((d->Cout & 7) || (d->out_off & 7) || (d->out_px_stride & 7) || (d->out_row_stride & 7) || (d->out_img_stride & 7)))

@@ -49,6 +49,36 @@ __global__ void __launch_bounds__(256) maxpool2_fwd_kernel(const bf16_t *__restr
     *reinterpret_cast<uint4 *>(y + (((long)n * Hop + oy + ho) * Wop + ox + ho) * C + c8 * 8) = pack8(m);
 }
 
+// MaxPool2d(3, stride 2, pad 1) on a non-negative input (zero halo == -inf padding): one thread = one
+// output pixel x 8 channels, 9 x 16-B loads
+__global__ void __launch_bounds__(256) maxpool3s2_fwd_kernel(const bf16_t *__restrict__ x, int N, int H, int W, int C, int hi, int ho,
+                                                             bf16_t *__restrict__ y)
+{
+    const int C8 = C >> 3, Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+    const long total = (long)N * Ho * Wo * C8;
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int c8 = (int)(idx % C8);
+    const int ox = (int)((idx / C8) % Wo);
+    const int oy = (int)((idx / ((long)C8 * Wo)) % Ho);
+    const int n = (int)(idx / ((long)C8 * Wo * Ho));
+    const int Wp = W + 2 * hi, Hp = H + 2 * hi;
+    // window rows 2*oy-1 .. 2*oy+1 in logical coordinates -> +hi in the buffer (hi >= 1)
+    const bf16_t *p = x + (((long)n * Hp + 2 * oy - 1 + hi) * Wp + 2 * ox - 1 + hi) * C + c8 * 8;
+    float m[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+            float v[8];
+            unpack8(*reinterpret_cast<const uint4 *>(p + ((long)dy * Wp + dx) * C), v);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) m[k] = fmaxf(m[k], v[k]);
+        }
+    const int Wop = Wo + 2 * ho, Hop = Ho + 2 * ho;
+    *reinterpret_cast<uint4 *>(y + (((long)n * Hop + oy + ho) * Wop + ox + ho) * C + c8 * 8) = pack8(m);
+}
+
 // one thread = one pooled pixel x 8 channels; writes the four un-pooled gradient pixels
 __global__ void __launch_bounds__(256) maxpool2_bwd_kernel(const bf16_t *__restrict__ yfull, const bf16_t *__restrict__ dpool, int N, int H,
                                                            int W, int C, int hi, int ho, float slope, bf16_t *__restrict__ dz)
@@ -120,4 +150,15 @@ YOLO_API int yolo_maxpool2_bwd_lrelu(const yolo_pool_desc *d, const void *yfull,
     hipLaunchKernelGGL(maxpool2_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, STRM(stream), (const bf16_t *)yfull, (const bf16_t *)dpool,
                        d->N, d->H, d->W, d->C, d->in_halo, d->out_halo, slope, (bf16_t *)dz);
     return check_launch("yolo_maxpool2_bwd_lrelu");
+}
+
+YOLO_API int yolo_maxpool3s2_fwd(const yolo_pool_desc *d, const void *x, void *y, yolo_stream_t stream)
+{
+    if (!d || !x || !y || d->N <= 0 || d->H <= 0 || d->W <= 0 || d->C <= 0 || d->in_halo < 1 || d->out_halo < 0) return fail(YOLO_E_ARG, "yolo_maxpool3s2_fwd: bad argument (input halo >= 1)");
+    if (d->C & 7) return fail(YOLO_E_UNSUPPORTED, "yolo_maxpool3s2_fwd: C must be a multiple of 8");
+    const int Ho = (d->H - 1) / 2 + 1, Wo = (d->W - 1) / 2 + 1;
+    const long total = (long)d->N * Ho * Wo * (d->C / 8);
+    hipLaunchKernelGGL(maxpool3s2_fwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, STRM(stream), (const bf16_t *)x, d->N, d->H, d->W, d->C,
+                       d->in_halo, d->out_halo, (bf16_t *)y);
+    return check_launch("yolo_maxpool3s2_fwd");
 }

@@ -59,7 +59,7 @@ class PoolDesc(ctypes.Structure):
                 ("in_halo", ctypes.c_int32), ("out_halo", ctypes.c_int32)]
 
 
-EPI_NONE, EPI_BIAS, EPI_BIAS_LRELU, EPI_MUL_DLRELU = 0, 1, 2, 3
+EPI_NONE, EPI_BIAS, EPI_BIAS_LRELU, EPI_MUL_DLRELU, EPI_BIAS_ADD_LRELU = 0, 1, 2, 3, 4
 NMS_INFERENCE, NMS_METRICS = 0, 1
 
 # name -> argtypes ; every symbol include/yolo_hip.h declares (tests check the list against the header)
@@ -73,6 +73,7 @@ _SIGS = {
     "yolo_loss_iou": [c_void_p, c_void_p, c_long, c_void_p, c_void_p],
     "yolo_igemm": [ctypes.POINTER(IgemmDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
     "yolo_wgrad": [ctypes.POINTER(WgradDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
+    "yolo_maxpool3s2_fwd": [ctypes.POINTER(PoolDesc), c_void_p, c_void_p, c_void_p],
     "yolo_maxpool2_fwd": [ctypes.POINTER(PoolDesc), c_void_p, c_void_p, c_void_p],
     "yolo_maxpool2_bwd_lrelu": [ctypes.POINTER(PoolDesc), c_void_p, c_void_p, c_float, c_void_p, c_void_p],
     "yolo_nchw_f32_to_nhwc_bf16": [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p],

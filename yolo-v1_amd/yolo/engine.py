@@ -624,3 +624,126 @@ def run_plan(plan: Plan, x: torch.Tensor, drop_training: bool) -> torch.Tensor:
     # grad mode must be sampled here: inside Function.forward it is always off
     need = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in plan.params))
     return PlanFunction.apply(plan, drop_training, need, x, *plan.params)
+
+
+# ====================================================================================================
+# ResNet-50 trunk, inference only (BatchNorm folded into the conv that precedes it)
+# ====================================================================================================
+class ResNetPlan:
+    """Inference executor for ``yolo.resnet.resnet50_trunk`` on the same kernels: every conv+BN(+ReLU) is
+    one yolo_igemm (BN folded into the bf16 weights and an fp32 bias at pack time), the residual add + ReLU
+    of a bottleneck is the epilogue of its last 1x1 conv (YOLO_EPI_BIAS_ADD_LRELU with slope 0), the stem's
+    MaxPool2d(3,2,1) is yolo_maxpool3s2_fwd.  Training-mode BatchNorm (batch statistics) is not built."""
+
+    def __init__(self, trunk: nn.Sequential):
+        self.trunk = trunk
+        self._packed = None
+        self._bufs: dict = {}
+
+    # -- BN folding: y = gamma * (conv(x) - mean) / sqrt(var + eps) + beta
+    @staticmethod
+    def _fold(conv: nn.Conv2d, bn: nn.BatchNorm2d):
+        scale = bn.weight.detach().float() / torch.sqrt(bn.running_var.detach().float() + bn.eps)
+        w = conv.weight.detach().float() * scale.view(-1, 1, 1, 1)
+        b = bn.bias.detach().float() - bn.running_mean.detach().float() * scale
+        if conv.bias is not None:
+            b = b + conv.bias.detach().float() * scale
+        return w.contiguous(), b.contiguous()
+
+    def _pack_all(self):
+        ver = tuple(int(p._version) for p in self.trunk.parameters()) + tuple(int(b._version) for b in self.trunk.buffers())
+        if self._packed is not None and self._packed[0] == ver:
+            return self._packed[1]
+        st = stream()
+        out = {}
+
+        def pack(name, conv, bn, first=False):
+            w, b = self._fold(conv, bn)
+            co, ci, k, _ = w.shape
+            if first:
+                wf = torch.empty((co, 7, 8, 4), dtype=torch.bfloat16, device=w.device)
+                check(lib().yolo_pack_conv_weight(ptr(w), co, 3, 7, 7, 4, 8, ptr(wf), None, st), "pack stem")
+            else:
+                wf = torch.empty((co, k, k, ci), dtype=torch.bfloat16, device=w.device)
+                check(lib().yolo_pack_conv_weight(ptr(w), co, ci, k, k, ci, k, ptr(wf), None, st), "pack")
+            out[name] = (wf, b, conv)
+
+        pack("stem", self.trunk[0], self.trunk[1], first=True)
+        for li in range(4, 8):
+            for bi, blk in enumerate(self.trunk[li]):
+                pack((li, bi, 1), blk.conv1, blk.bn1)
+                pack((li, bi, 2), blk.conv2, blk.bn2)
+                pack((li, bi, 3), blk.conv3, blk.bn3)
+                if blk.downsample is not None:
+                    pack((li, bi, "d"), blk.downsample[0], blk.downsample[1])
+        self._packed = (ver, out)
+        return out
+
+    def _act(self, key, N, H, W, C, halo, dev):
+        k = (key, N, H, W, C, halo, str(dev))
+        a = self._bufs.get(k)
+        if a is None:
+            a = Act(N, H, W, C, halo, dev)
+            self._bufs[k] = a
+        return a
+
+    def _conv(self, tag, a_in: Act, packed, N, relu: bool, residual: Act | None, dev, st):
+        wf, b, conv = packed
+        k, s, p = conv.kernel_size[0], conv.stride[0], conv.padding[0]
+        Ho, Wo = (a_in.H + 2 * p - k) // s + 1, (a_in.W + 2 * p - k) // s + 1
+        a_out = self._act(tag, N, Ho, Wo, conv.out_channels, 1, dev)
+        d = IgemmDesc()
+        d.N, d.Ho, d.Wo = N, Ho, Wo
+        d.in_img_stride, d.in_row_stride, d.in_px_stride = a_in.img_stride, a_in.row_stride, a_in.px_stride
+        d.in_off = a_in.interior_off(p)
+        d.stride, d.KH, d.KW, d.tap_len, d.Cout = s, k, k, conv.in_channels, conv.out_channels
+        d.out_img_stride, d.out_row_stride, d.out_px_stride, d.out_off = a_out.img_stride, a_out.row_stride, a_out.px_stride, a_out.interior_off()
+        d.slope = 0.0 if relu else 1.0
+        aux = None
+        if residual is not None:
+            d.epilogue = _hip.EPI_BIAS_ADD_LRELU
+            d.aux_img_stride, d.aux_row_stride, d.aux_px_stride, d.aux_off = residual.img_stride, residual.row_stride, residual.px_stride, residual.interior_off()
+            aux = residual.p
+        else:
+            d.epilogue = EPI_BIAS_LRELU if relu else EPI_BIAS
+        with _timed(str(tag), "igemm", 2.0 * N * Ho * Wo * conv.out_channels * conv.in_channels * k * k):
+            check(lib().yolo_igemm(ctypes.byref(d), a_in.p, ptr(wf), ptr(b), aux, a_out.p, st), f"igemm {tag}")
+        return a_out
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        """(N,3,H,W) fp32 on the device -> (N,2048,H/32,W/32) fp32."""
+        _hip.require_cuda(x)
+        st = stream()
+        pk = self._pack_all()
+        N, _, H, W = x.shape
+        dev = x.device
+        x = x.detach()
+        if x.dtype != torch.float32 or not x.is_contiguous():
+            x = x.float().contiguous()
+        a = self._act("in", N, H, W, 4, 3, dev)
+        check(lib().yolo_nchw_f32_to_nhwc_bf16(ptr(x), N, 3, H, W, a.p, 4, 3, 3, st), "nchw->nhwc4")
+        # stem: 7x7/s2 (+BN+ReLU) as the row-segment implicit GEMM, then MaxPool2d(3,2,1)
+        wf, b, conv = pk["stem"]
+        Ho, Wo = (H + 6 - 7) // 2 + 1, (W + 6 - 7) // 2 + 1
+        s1 = self._act("stem", N, Ho, Wo, 64, 1, dev)
+        d = IgemmDesc()
+        d.N, d.Ho, d.Wo = N, Ho, Wo
+        d.in_img_stride, d.in_row_stride, d.in_px_stride, d.in_off = a.img_stride, a.row_stride, a.px_stride, 0
+        d.stride, d.KH, d.KW, d.tap_len, d.Cout = 2, 7, 1, 32, 64
+        d.out_img_stride, d.out_row_stride, d.out_px_stride, d.out_off = s1.img_stride, s1.row_stride, s1.px_stride, s1.interior_off()
+        d.epilogue, d.slope = EPI_BIAS_LRELU, 0.0
+        with _timed("stem", "igemm", 2.0 * N * Ho * Wo * 64 * 147):
+            check(lib().yolo_igemm(ctypes.byref(d), a.p, ptr(wf), ptr(b), None, s1.p, st), "igemm stem")
+        Hq, Wq = (Ho - 1) // 2 + 1, (Wo - 1) // 2 + 1
+        cur = self._act("pool", N, Hq, Wq, 64, 1, dev)
+        pd = PoolDesc(N, Ho, Wo, 64, 1, 1)
+        check(lib().yolo_maxpool3s2_fwd(ctypes.byref(pd), s1.p, cur.p, st), "maxpool3s2")
+        for li in range(4, 8):
+            for bi, blk in enumerate(self.trunk[li]):
+                idn = cur if blk.downsample is None else self._conv((li, bi, "d"), cur, pk[(li, bi, "d")], N, False, None, dev, st)
+                t = self._conv((li, bi, 1), cur, pk[(li, bi, 1)], N, True, None, dev, st)
+                t = self._conv((li, bi, 2), t, pk[(li, bi, 2)], N, True, None, dev, st)
+                cur = self._conv((li, bi, 3), t, pk[(li, bi, 3)], N, True, idn, dev, st)
+        out = torch.empty((N, cur.C, cur.H, cur.W), dtype=torch.float32, device=dev)
+        check(lib().yolo_nhwc_bf16_to_nchw_f32(cur.p, N, cur.C, cur.H, cur.W, cur.halo, ptr(out), st), "nhwc->nchw")
+        return out

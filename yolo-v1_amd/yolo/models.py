@@ -74,26 +74,40 @@ class YOLOv1Backbone(Backbone):
 
 
 class ResNetBackbone(Backbone):
-    """ResNet50 trunk up to layer4 (2048 x 14 x 14 for 448 x 448 inputs).
+    """ResNet50 trunk up to layer4 (2048 x 14 x 14 for 448 x 448 inputs), reference src/yolo/models.py:131-176.
 
-    The reference wraps ``torchvision.models.resnet50`` (src/yolo/models.py:131-176); torchvision is
-    an un-vendored dependency whose arithmetic is outside the reference, so this class needs it at
-    construction time and is outside the HIP hot path of this round (ResNet50
-    numerics are "parity unpinned")."""
+    The reference wraps ``torchvision.models.resnet50``; torchvision is an un-vendored dependency, so the
+    trunk is restated in ``yolo.resnet`` with torchvision's module names (``extractor.N...`` state_dict keys
+    are the reference's).  ``pretrained=True`` needs the ImageNet weights, i.e. torchvision + a download.
+    Device tensors in eval mode run on the HIP engine (BatchNorm folded, residual add fused); training-mode
+    BatchNorm on the device is not built this round."""
 
     def __init__(self, pretrained: bool = True, freeze: bool = True):
         super().__init__()
-        try:
-            from torchvision.models import ResNet50_Weights, resnet50
-        except ImportError as e:  # pragma: no cover - torchvision is absent in the build image
-            raise ImportError("ResNetBackbone needs torchvision (reference dependency, not vendored)") from e
-        net = resnet50(weights=ResNet50_Weights.DEFAULT if pretrained else None)
+        from .resnet import resnet50_trunk
+        trunk = resnet50_trunk()
+        if pretrained:
+            try:
+                from torchvision.models import ResNet50_Weights, resnet50
+            except ImportError as e:
+                raise ImportError("ResNetBackbone(pretrained=True) needs torchvision's ImageNet weights; "
+                                  "use pretrained=False or load a checkpoint") from e
+            tv = nn.Sequential(*list(resnet50(weights=ResNet50_Weights.DEFAULT).children())[:-2])
+            trunk.load_state_dict(tv.state_dict())
         if freeze:
-            for p in net.parameters():
+            for p in trunk.parameters():
                 p.requires_grad = False
-        self.extractor = nn.Sequential(*list(net.children())[:-2])
+        self.extractor = trunk
+        self._plan = None
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
+        if x.is_cuda:
+            if self.training or (torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())):
+                raise NotImplementedError("ResNetBackbone on the HIP engine is inference-only this round: call .eval() and "
+                                          "run under torch.no_grad() (or freeze the backbone)")
+            if self._plan is None:
+                self._plan = engine.ResNetPlan(self.extractor)
+            return self._plan.forward(x)
         return self.extractor(x)
 
 
