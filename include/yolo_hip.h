@@ -133,6 +133,7 @@ typedef struct yolo_igemm_desc {
     int32_t pool2;          /* 1: fuse MaxPool2d(2,2) into the epilogue (conv -> LeakyReLU -> pool, models.py:49-55):
                                Ho/Wo stay the CONV output size, out_* address the pooled map [Ho/2][Wo/2]     */
     int32_t w_blocked;      /* 1: w is in the panel layout of yolo_pack_fc_weight_blocked (Linear layers)      */
+    int32_t tile_order;     /* 0 = heuristic; 1 = channel tiles fastest; 2 = pixel tiles fastest inside an XCD's range   */
     int32_t tile_hint;      /* 0 = let the library pick the tile configuration; 1: 128x128, 2: 256x128
                                (8 waves, 3 stages), 3: 128x64, 4: 64x128, 5/6: 1/2 on the 16x16x32
                                MFMA shape  (tuning / tests)                                        */

@@ -45,7 +45,8 @@ for item in synth.YOLOV1_BACKBONE_CFG:
     fl = 2.0 * N * h * h * co * ci * k * k
     line = f"idx {idx:2d} co {co:4d} ci {ci:4d} k {k} s {s} out {h:3d} M {N*h*h:7d} K {ci*k*k:5d} |"
     for hint in hints:
-        d.tile_hint = hint
+        d.tile_hint = hint % 100
+        d.tile_order = hint // 100
         try:
             for _ in range(2):
                 check(lib().yolo_igemm(ctypes.byref(d), x.p, ptr(w), ptr(b), None, y.p, stream()))

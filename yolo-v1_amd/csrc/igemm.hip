@@ -33,7 +33,7 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
-enum { MFMA_32x32x16 = 0, MFMA_16x16x32 = 1 };
+enum { MFMA_32x32x16 = 0, MFMA_16x16x32 = 1, MFMA_16x16x32_STAGGER = 2 };
 
 struct IgemmParams {
     const bf16_t *in;
@@ -59,6 +59,7 @@ struct IgemmParams {
     int nk;                 // K iterations in total
     int nk_per_split;
     int n_co_tiles, n_px_tiles;
+    int px_fastest;         // tile order inside an XCD's contiguous range: 1 = pixel tiles fastest (one weight panel per XCD)
 };
 
 #define GLDS16(gptr, lptr) \
@@ -89,15 +90,16 @@ struct IgemmCfg {
     static constexpr int B_BYTES = TPX * BK * 2;
     static constexpr int STAGE_BYTES = A_BYTES + B_BYTES;
     static constexpr int EP = TCO + 4;                       // fp32 epilogue row pitch (floats)
-    static constexpr int EPI_BYTES = TPX * EP * 4;
+    static constexpr int PPX = TPX / WPX;                    // pixels per epilogue pass (one wave column)
+    static constexpr int EPI_BYTES = PPX * EP * 4;
     static constexpr int TABLE_BYTES = TPX * 32;             // per pixel: in_base, out_base, aux_base (int64 each, padded to 4)
     static constexpr int MAIN_BYTES = (NST * STAGE_BYTES > EPI_BYTES) ? NST * STAGE_BYTES : EPI_BYTES;
     static constexpr int LDS_BYTES = TABLE_BYTES + MAIN_BYTES;
     static constexpr int A_INSTR = A_BYTES / 1024 / NW;      // glds wave-instructions per wave per stage
     static constexpr int B_INSTR = B_BYTES / 1024 / NW;
     static constexpr int LOADS = A_INSTR + B_INSTR;
-    static constexpr int FR = MF == MFMA_16x16x32 ? 16 : 32;        // MFMA tile edge
-    static constexpr int KS = MF == MFMA_16x16x32 ? 32 : 16;        // K per MFMA
+    static constexpr int FR = MF != MFMA_32x32x16 ? 16 : 32;        // MFMA tile edge
+    static constexpr int KS = MF != MFMA_32x32x16 ? 32 : 16;        // K per MFMA
     static constexpr int MT = TCO / WCO / FR, NT = TPX / WPX / FR;  // MFMA tiles per wave
     static_assert(A_BYTES % (1024 * NW) == 0 && B_BYTES % (1024 * NW) == 0, "stage must split evenly over the waves");
     static_assert(TPX <= NTHR, "one table entry per thread");
@@ -107,7 +109,8 @@ template <int TCO, int TPX, int BK, int WCO, int WPX, int NST, int MF>
 __global__ void __launch_bounds__(WCO * WPX * 64, 2) igemm_kernel(const IgemmParams p)
 {
     using Cfg = IgemmCfg<TCO, TPX, BK, WCO, WPX, NST, MF>;
-    constexpr bool M16 = MF == MFMA_16x16x32;
+    constexpr bool M16 = MF != MFMA_32x32x16;
+    constexpr bool STG = MF == MFMA_16x16x32_STAGGER;
     constexpr int FR = Cfg::FR;
     constexpr int MT = Cfg::MT, NT = Cfg::NT, NW = Cfg::NW, NTHR = Cfg::NTHR;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -128,7 +131,8 @@ __global__ void __launch_bounds__(WCO * WPX * 64, 2) igemm_kernel(const IgemmPar
         const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, k = bid >> 3;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
     }
-    const int co_tile = bid % p.n_co_tiles, px_tile = bid / p.n_co_tiles;
+    const int co_tile = p.px_fastest ? bid / p.n_px_tiles : bid % p.n_co_tiles;
+    const int px_tile = p.px_fastest ? bid % p.n_px_tiles : bid / p.n_co_tiles;
     const int co0 = co_tile * TCO;
     const long px0 = (long)px_tile * TPX;
 
@@ -248,6 +252,104 @@ __global__ void __launch_bounds__(WCO * WPX * 64, 2) igemm_kernel(const IgemmPar
     // flight across the barrier: each wave waits only for ITS loads of the stage about to be read
     // (counted vmcnt), then the raw barrier makes every wave's part of that stage visible and proves
     // that everyone has finished reading the stage that is overwritten next.
+    constexpr int KSTEPS = BK / Cfg::KS;
+    constexpr int KSH = M16 ? 6 : 5;   // the k-step only touches chunk-index bits that the row part left clear -> XOR
+    auto read_frags = [&](int buf, bf16x8(&af)[KSTEPS][MT], bf16x8(&bfr)[KSTEPS][NT]) {
+        const char *sb = stage_base + buf * Cfg::STAGE_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ++ks) {
+#pragma unroll
+            for (int i = 0; i < MT; ++i) af[ks][i] = *reinterpret_cast<const bf16x8 *>(sb + (a_rd[i] ^ (ks << KSH)));
+#pragma unroll
+            for (int j = 0; j < NT; ++j) bfr[ks][j] = *reinterpret_cast<const bf16x8 *>(sb + (b_rd[j] ^ (ks << KSH)));
+        }
+    };
+    auto mfmas = [&](bf16x8(&af)[KSTEPS][MT], bf16x8(&bfr)[KSTEPS][NT]) {
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ++ks)
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    if constexpr (M16) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[ks][i], bfr[ks][j], acc[i][j], 0, 0, 0);
+                    else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks][i], bfr[ks][j], acc[i][j], 0, 0, 0);
+                }
+    };
+
+    if constexpr (STG) {
+        // ---- staggered two-phase schedule (8 waves, 3-stage ring).  Each K step is split into an L phase
+        // (all fragment reads of the step -> registers) and an M phase (all its MFMAs), separated by raw
+        // barriers.  Waves 0..3 (group A) and 4..7 (group B) sit pairwise on the same SIMDs and run ONE
+        // PHASE APART, so on every SIMD one wave feeds the matrix pipe while its partner reads LDS:
+        //     slot:   0     1     2     3     4 ...
+        //     A:      L0    M0    L1    M1    L2
+        //     B:      -     L0    M0    L1    M1
+        // Global->LDS loads of stage s are issued by everybody in slot 2(s-2) (A in L, B in M) and each wave
+        // drains its own part with a counted vmcnt at the end of slot 2s-1, one barrier before the first
+        // reader (A in slot 2s).  Buffer (s mod 3) was last read in slot 2(s-3)+1, two barriers earlier.
+        static_assert(!STG || (NST >= 3 && NW == 8), "stagger needs 8 waves and a ring of >= 3 stages");
+        // general ring of NST stages (D = NST-1 stages of distance): stage s is issued in slot 2(s-D), must
+        // have landed by the end of slot 2s-1; at that wait D-1 younger stages may stay in flight.
+        constexpr int D = NST - 1;
+        const bool grpB = wave >= NW / 2;
+        const int nkk = kend - kbeg;
+#pragma unroll
+        for (int s0 = 0; s0 < D; ++s0)
+            if (s0 < nkk) stage(s0, kbeg + s0);
+        auto wait_stage = [&](int newer) {   // newer = younger stages this wave has already issued
+            if (newer >= D - 1) wait_vmcnt<(D - 1) * Cfg::LOADS>();
+            else if (newer == 1 && D - 1 > 1) wait_vmcnt<Cfg::LOADS>();
+            else wait_vmcnt<0>();
+        };
+        wait_stage(nkk - 1 < D - 1 ? nkk - 1 : D - 1);   // stage 0 landed
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        bf16x8 af[KSTEPS][MT], bfr[KSTEPS][NT];
+        int rd_buf = 0;
+        if (!grpB) {
+            int ld_buf = D % NST;
+            for (int it = 0; it < nkk; ++it) {
+                read_frags(rd_buf, af, bfr);                                     // L(it)   (even slot)
+                if (it + D < nkk) stage(ld_buf, kbeg + it + D);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_setprio(1);
+                mfmas(af, bfr);                                                  // M(it)   (odd slot)
+                __builtin_amdgcn_s_setprio(0);
+                { const int left = nkk - 2 - it; wait_stage(left < 0 ? 0 : left); }   // stage it+1 landed
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+                rd_buf = rd_buf + 1 == NST ? 0 : rd_buf + 1;
+                ld_buf = ld_buf + 1 == NST ? 0 : ld_buf + 1;
+            }
+            __builtin_amdgcn_s_barrier();
+        } else {
+            if (D < nkk) stage(D % NST, kbeg + D);                               // slot 0
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            int ld_buf = (D + 1) % NST;
+            for (int it = 0; it < nkk; ++it) {
+                read_frags(rd_buf, af, bfr);                                     // L(it)   (odd slot)
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                { const int left = nkk - 2 - it; wait_stage(left < 0 ? 0 : left); }   // stage it+1 landed
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+                if (it + D + 1 < nkk) stage(ld_buf, kbeg + it + D + 1);          // M(it)   (even slot)
+                __builtin_amdgcn_s_setprio(1);
+                mfmas(af, bfr);
+                __builtin_amdgcn_s_setprio(0);
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+                rd_buf = rd_buf + 1 == NST ? 0 : rd_buf + 1;
+                ld_buf = ld_buf + 1 == NST ? 0 : ld_buf + 1;
+            }
+        }
+    } else {
     constexpr int D = NST - 1;
 #pragma unroll
     for (int s0 = 0; s0 < D; ++s0)
@@ -259,151 +361,162 @@ __global__ void __launch_bounds__(WCO * WPX * 64, 2) igemm_kernel(const IgemmPar
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         if (it + D < kend) stage(nxt, it + D);
+        bf16x8 af[KSTEPS][MT], bfr[KSTEPS][NT];
         const char *sb = stage_base + cur * Cfg::STAGE_BYTES;
 #pragma unroll
-        for (int ks = 0; ks < BK / Cfg::KS; ++ks) {
-            bf16x8 af[MT], bfr[NT];
-            // the k-step only touches chunk-index bits that the row part left clear -> XOR on the byte offset
-            constexpr int KSH = M16 ? 6 : 5;
+        for (int ks = 0; ks < KSTEPS; ++ks) {
 #pragma unroll
-            for (int i = 0; i < MT; ++i) af[i] = *reinterpret_cast<const bf16x8 *>(sb + (a_rd[i] ^ (ks << KSH)));
+            for (int i = 0; i < MT; ++i) af[0][i] = *reinterpret_cast<const bf16x8 *>(sb + (a_rd[i] ^ (ks << KSH)));
 #pragma unroll
-            for (int j = 0; j < NT; ++j) bfr[j] = *reinterpret_cast<const bf16x8 *>(sb + (b_rd[j] ^ (ks << KSH)));
+            for (int j = 0; j < NT; ++j) bfr[0][j] = *reinterpret_cast<const bf16x8 *>(sb + (b_rd[j] ^ (ks << KSH)));
 #pragma unroll
             for (int i = 0; i < MT; ++i)
 #pragma unroll
                 for (int j = 0; j < NT; ++j) {
-                    if constexpr (M16) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
-                    else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+                    if constexpr (M16) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0][i], bfr[0][j], acc[i][j], 0, 0, 0);
+                    else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bfr[0][j], acc[i][j], 0, 0, 0);
                 }
         }
         cur = (cur + 1 == NST) ? 0 : cur + 1;
         nxt = (nxt + 1 == NST) ? 0 : nxt + 1;
     }
+    }
     __syncthreads();  // all MFMA operand reads done before the stage area is reused for the epilogue
 
-    // ---- epilogue 1: accumulators -> LDS fp32 [px][co]
-    // 32x32 C/D map: col (= pixel) = lane&31, row (= co) = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+    // ---- epilogue, in WPX passes of PPX = TPX/WPX pixels (keeps the fp32 staging tile small: the 256-wide
+    // tiles would not fit otherwise).  Pass q: the waves of pixel column q put their accumulators into LDS as
+    // fp32 [px][co]; then ALL threads stream that slab out, 8 channels (16 B of bf16) per thread per step.
+    //   32x32 C/D map: col (= pixel) = lane&31, row (= co) = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+    //   16x16 C/D map: col (= pixel) = lane&15, row (= co) = 4*(lane>>4) + reg
     float *ep = reinterpret_cast<float *>(stage_base);
-    // 16x16 C/D map: col (= pixel) = lane&15, row (= co) = 4*(lane>>4) + reg
-#pragma unroll
-    for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int j = 0; j < NT; ++j) {
-            if constexpr (M16) {
-                const int px = wpx * (TPX / WPX) + j * 16 + (lane & 15);
-                const int cob = wco * (TCO / WCO) + i * 16 + 4 * (lane >> 4);
-                f32x4 v = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-                *reinterpret_cast<f32x4 *>(ep + px * Cfg::EP + cob) = v;
-            } else {
-                const int px = wpx * (TPX / WPX) + j * 32 + (lane & 31);
-                const int cob = wco * (TCO / WCO) + i * 32 + 4 * (lane >> 5);
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    f32x4 v = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
-                    *reinterpret_cast<f32x4 *>(ep + px * Cfg::EP + cob + 8 * g) = v;
-                }
-            }
-        }
-    __syncthreads();
-
-    // ---- epilogue 2: coalesced along channels, 8 channels per thread per step
-    constexpr int CCH = TCO / 8;            // 8-channel chunks per pixel
+    constexpr int PPX = Cfg::PPX;
+    constexpr int CCH = TCO / 8;             // 8-channel chunks per pixel
     constexpr int PX_PER_STEP = NTHR / CCH;  // pixels covered by the workgroup per step
     const int cc = tid % CCH;
     const int co = co0 + cc * 8;
+    const bool has_bias = p.epilogue == YOLO_EPI_BIAS || p.epilogue == YOLO_EPI_BIAS_LRELU || p.epilogue == YOLO_EPI_BIAS_ADD_LRELU;
     float bias8[8];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) bias8[k] = (p.epilogue == YOLO_EPI_BIAS || p.epilogue == YOLO_EPI_BIAS_LRELU || p.epilogue == YOLO_EPI_BIAS_ADD_LRELU) && (co + k < p.Cout) ? p.bias[co + k] : 0.0f;
+    for (int k = 0; k < 8; ++k) bias8[k] = has_bias && (co + k < p.Cout) ? p.bias[co + k] : 0.0f;
     const bool split = gridDim.y > 1;
-    if (split) {
-        // split-K partial tile: fp32 atomics shaped as 256 contiguous bytes per wave-instruction (one
-        // dword per lane along the channel axis) -- the fast form of global_atomic_add_f32
-        float *o = reinterpret_cast<float *>(p.out);
-        for (int e = tid; e < TPX * TCO; e += NTHR) {
-            const int px = e / TCO, c = e - px * TCO;
-            const long ob = tab[4 * px + 1];
-            if (ob >= 0 && co0 + c < p.Cout) atomicAdd(o + ob + co0 + c, ep[px * Cfg::EP + c]);
+
+    for (int q = 0; q < WPX; ++q) {
+        if (q > 0) __syncthreads();   // the previous slab has been streamed out
+        if (wpx == q) {
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    if constexpr (M16) {
+                        const int lp = j * 16 + (lane & 15);
+                        const int cob = wco * (TCO / WCO) + i * 16 + 4 * (lane >> 4);
+                        f32x4 v = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+                        *reinterpret_cast<f32x4 *>(ep + lp * Cfg::EP + cob) = v;
+                    } else {
+                        const int lp = j * 32 + (lane & 31);
+                        const int cob = wco * (TCO / WCO) + i * 32 + 4 * (lane >> 5);
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            f32x4 v = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+                            *reinterpret_cast<f32x4 *>(ep + lp * Cfg::EP + cob + 8 * g) = v;
+                        }
+                    }
+                }
         }
-        return;
-    }
-    if (p.pool) {
-        // fused MaxPool2d(2,2): max over the window's four LDS rows, then bias + LeakyReLU (monotone, so
-        // pool(lrelu(z + b)) == lrelu(max(z) + b)); one 16-B store per pooled pixel and channel chunk
-        const int tw = p.pool_tw, hw = tw >> 1;
-        for (int q = tid / CCH; q < TPX / 4; q += PX_PER_STEP) {
-            const int l00 = (q / hw) * 2 * tw + (q % hw) * 2;
-            const long ob = tab[4 * l00 + 1];
+        __syncthreads();
+        const int pbase = q * PPX;   // first tile pixel of this slab
+
+        if (split) {
+            // split-K partial tile: fp32 atomics shaped as 256 contiguous bytes per wave-instruction (one
+            // dword per lane along the channel axis) -- the fast form of global_atomic_add_f32
+            float *o = reinterpret_cast<float *>(p.out);
+            for (int e = tid; e < PPX * TCO; e += NTHR) {
+                const int lp = e / TCO, c = e - lp * TCO;
+                const long ob = tab[4 * (pbase + lp) + 1];
+                if (ob >= 0 && co0 + c < p.Cout) atomicAdd(o + ob + co0 + c, ep[lp * Cfg::EP + c]);
+            }
+            continue;
+        }
+        if (p.pool) {
+            // fused MaxPool2d(2,2): max over the window's four LDS rows, then bias + LeakyReLU (monotone, so
+            // pool(lrelu(z + b)) == lrelu(max(z) + b)); one 16-B store per pooled pixel and channel chunk.
+            // A slab is PPX/pool_tw full rows of the 8 x 16 patch, so every window lies inside one slab.
+            const int tw = p.pool_tw, hw = tw >> 1;
+            for (int w = tid / CCH; w < PPX / 4; w += PX_PER_STEP) {
+                const int l00 = (w / hw) * 2 * tw + (w % hw) * 2;
+                const long ob = tab[4 * (pbase + l00) + 1];
+                if (ob < 0 || co >= p.Cout) continue;
+                float v[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const float a = ep[l00 * Cfg::EP + cc * 8 + k], b = ep[(l00 + 1) * Cfg::EP + cc * 8 + k];
+                    const float c = ep[(l00 + tw) * Cfg::EP + cc * 8 + k], d = ep[(l00 + tw + 1) * Cfg::EP + cc * 8 + k];
+                    float m = fmaxf(fmaxf(a, b), fmaxf(c, d)) + bias8[k];
+                    v[k] = (p.epilogue == YOLO_EPI_BIAS_LRELU && m < 0.0f) ? m * p.slope : m;
+                }
+                uint4 pk;
+                pk.x = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
+                pk.y = (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
+                pk.z = (unsigned)f32_to_bf16(v[4]) | ((unsigned)f32_to_bf16(v[5]) << 16);
+                pk.w = (unsigned)f32_to_bf16(v[6]) | ((unsigned)f32_to_bf16(v[7]) << 16);
+                *reinterpret_cast<uint4 *>(reinterpret_cast<bf16_t *>(p.out) + ob + co) = pk;
+            }
+            continue;
+        }
+#pragma unroll 2
+        for (int lp = tid / CCH; lp < PPX; lp += PX_PER_STEP) {
+            const int px = pbase + lp;
+            const long ob = tab[4 * px + 1];
             if (ob < 0 || co >= p.Cout) continue;
             float v[8];
+            const f32x4 lo = *reinterpret_cast<const f32x4 *>(ep + lp * Cfg::EP + cc * 8);
+            const f32x4 hi = *reinterpret_cast<const f32x4 *>(ep + lp * Cfg::EP + cc * 8 + 4);
+            v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3];
+            v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
+            if (has_bias) {
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const float a = ep[l00 * Cfg::EP + cc * 8 + k], b = ep[(l00 + 1) * Cfg::EP + cc * 8 + k];
-                const float c = ep[(l00 + tw) * Cfg::EP + cc * 8 + k], d = ep[(l00 + tw + 1) * Cfg::EP + cc * 8 + k];
-                float m = fmaxf(fmaxf(a, b), fmaxf(c, d)) + bias8[k];
-                v[k] = (p.epilogue == YOLO_EPI_BIAS_LRELU && m < 0.0f) ? m * p.slope : m;
+                for (int k = 0; k < 8; ++k) v[k] += bias8[k];
             }
-            uint4 pk;
-            pk.x = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
-            pk.y = (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
-            pk.z = (unsigned)f32_to_bf16(v[4]) | ((unsigned)f32_to_bf16(v[5]) << 16);
-            pk.w = (unsigned)f32_to_bf16(v[6]) | ((unsigned)f32_to_bf16(v[7]) << 16);
-            *reinterpret_cast<uint4 *>(reinterpret_cast<bf16_t *>(p.out) + ob + co) = pk;
-        }
-        return;
-    }
-#pragma unroll 2
-    for (int px = tid / CCH; px < TPX; px += PX_PER_STEP) {
-        const long ob = tab[4 * px + 1];
-        if (ob < 0 || co >= p.Cout) continue;
-        float v[8];
-        const f32x4 lo = *reinterpret_cast<const f32x4 *>(ep + px * Cfg::EP + cc * 8);
-        const f32x4 hi = *reinterpret_cast<const f32x4 *>(ep + px * Cfg::EP + cc * 8 + 4);
-        v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3];
-        v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
-        if (p.epilogue == YOLO_EPI_BIAS || p.epilogue == YOLO_EPI_BIAS_LRELU || p.epilogue == YOLO_EPI_BIAS_ADD_LRELU) {
+            if (p.epilogue == YOLO_EPI_BIAS_ADD_LRELU) {
+                // residual branch (ResNet bottleneck): out = act(conv + bias + identity)
+                const uint4 y = *reinterpret_cast<const uint4 *>(p.aux + tab[4 * px + 2] + co);
+                const unsigned yy[4] = {y.x, y.y, y.z, y.w};
 #pragma unroll
-            for (int k = 0; k < 8; ++k) v[k] += bias8[k];
-        }
-        if (p.epilogue == YOLO_EPI_BIAS_ADD_LRELU) {
-            // residual branch (ResNet bottleneck): out = act(conv + bias + identity)
-            const uint4 y = *reinterpret_cast<const uint4 *>(p.aux + tab[4 * px + 2] + co);
-            const unsigned yy[4] = {y.x, y.y, y.z, y.w};
+                for (int k = 0; k < 8; ++k) {
+                    v[k] += __uint_as_float((k & 1) ? (yy[k >> 1] & 0xffff0000u) : (yy[k >> 1] << 16));
+                    v[k] = v[k] > 0.0f ? v[k] : v[k] * p.slope;
+                }
+            } else if (p.epilogue == YOLO_EPI_BIAS_LRELU) {
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                v[k] += __uint_as_float((k & 1) ? (yy[k >> 1] & 0xffff0000u) : (yy[k >> 1] << 16));
-                v[k] = v[k] > 0.0f ? v[k] : v[k] * p.slope;
+                for (int k = 0; k < 8; ++k) v[k] = v[k] > 0.0f ? v[k] : v[k] * p.slope;
+            } else if (p.epilogue == YOLO_EPI_MUL_DLRELU) {
+                const uint4 y = *reinterpret_cast<const uint4 *>(p.aux + tab[4 * px + 2] + co);
+                const unsigned yy[4] = {y.x, y.y, y.z, y.w};
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const float a = __uint_as_float((k & 1) ? (yy[k >> 1] & 0xffff0000u) : (yy[k >> 1] << 16));
+                    v[k] = a > 0.0f ? v[k] : v[k] * p.slope;
+                }
             }
-        } else if (p.epilogue == YOLO_EPI_BIAS_LRELU) {
+            if (p.out_fp32) {
+                float *o = reinterpret_cast<float *>(p.out) + ob + co;
+                if (co + 8 <= p.Cout && ((ob + co) & 3) == 0) {
+                    *reinterpret_cast<f32x4 *>(o) = f32x4{v[0], v[1], v[2], v[3]};
+                    *reinterpret_cast<f32x4 *>(o + 4) = f32x4{v[4], v[5], v[6], v[7]};
+                } else {
 #pragma unroll
-            for (int k = 0; k < 8; ++k) v[k] = v[k] > 0.0f ? v[k] : v[k] * p.slope;
-        } else if (p.epilogue == YOLO_EPI_MUL_DLRELU) {
-            const uint4 y = *reinterpret_cast<const uint4 *>(p.aux + tab[4 * px + 2] + co);
-            const unsigned yy[4] = {y.x, y.y, y.z, y.w};
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const float a = __uint_as_float((k & 1) ? (yy[k >> 1] & 0xffff0000u) : (yy[k >> 1] << 16));
-                v[k] = a > 0.0f ? v[k] : v[k] * p.slope;
-            }
-        }
-        if (p.out_fp32) {
-            float *o = reinterpret_cast<float *>(p.out) + ob + co;
-            if (co + 8 <= p.Cout && ((ob + co) & 3) == 0) {
-                *reinterpret_cast<f32x4 *>(o) = f32x4{v[0], v[1], v[2], v[3]};
-                *reinterpret_cast<f32x4 *>(o + 4) = f32x4{v[4], v[5], v[6], v[7]};
+                    for (int k = 0; k < 8; ++k)
+                        if (co + k < p.Cout) o[k] = v[k];
+                }
             } else {
-#pragma unroll
-                for (int k = 0; k < 8; ++k)
-                    if (co + k < p.Cout) o[k] = v[k];
+                bf16_t *o = reinterpret_cast<bf16_t *>(p.out) + ob + co;
+                uint4 pk;
+                pk.x = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
+                pk.y = (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
+                pk.z = (unsigned)f32_to_bf16(v[4]) | ((unsigned)f32_to_bf16(v[5]) << 16);
+                pk.w = (unsigned)f32_to_bf16(v[6]) | ((unsigned)f32_to_bf16(v[7]) << 16);
+                *reinterpret_cast<uint4 *>(o) = pk;  // Cout % 8 == 0 is required for bf16 outputs
             }
-        } else {
-            bf16_t *o = reinterpret_cast<bf16_t *>(p.out) + ob + co;
-            uint4 pk;
-            pk.x = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
-            pk.y = (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
-            pk.z = (unsigned)f32_to_bf16(v[4]) | ((unsigned)f32_to_bf16(v[5]) << 16);
-            pk.w = (unsigned)f32_to_bf16(v[6]) | ((unsigned)f32_to_bf16(v[7]) << 16);
-            *reinterpret_cast<uint4 *>(o) = pk;  // Cout % 8 == 0 is required for bf16 outputs
         }
     }
 }
@@ -428,6 +541,10 @@ static int launch(const IgemmParams &p, int splits, hipStream_t s)
         q.n_px_tiles = (int)((p.M + TPX - 1) / TPX);
     }
     q.nk = (int)(p.Ktot / BK);
+    // L2 working set: when the weights are much larger than an XCD's 4-MB L2, give each XCD its own weight
+    // panel(s) and let it stream the pixel tiles (activations are then read once per XCD instead of the whole
+    // weight tensor once per group of pixel tiles)
+    if (p.px_fastest < 0) q.px_fastest = 0;   // measured: channel-tiles-fastest is never slower on this network (tile_order overrides)
     q.nk_per_split = (q.nk + splits - 1) / splits;
     const int real_splits = (q.nk + q.nk_per_split - 1) / q.nk_per_split;
     hipLaunchKernelGGL((igemm_kernel<TCO, TPX, BK, WCO, WPX, NST, MF>), dim3(q.n_co_tiles * q.n_px_tiles, real_splits), dim3(Cfg::NTHR), Cfg::LDS_BYTES, s, q);
@@ -469,6 +586,7 @@ YOLO_API int yolo_igemm(const yolo_igemm_desc *d, const void *in, const void *w,
     const long tiles128 = ((p.M + 127) / 128) * ((d->Cout + 127) / 128);
     const int force = d->tile_hint;   // 0 = heuristic; tests / tuning may force a configuration
     p.w_blocked = d->w_blocked;
+    p.px_fastest = d->tile_order == 1 ? 0 : (d->tile_order == 2 ? 1 : -1);
     p.pool = d->pool2 ? 1 : 0;
     p.pool_tw = 16;
     if (p.pool && (splits > 1 || d->out_fp32 || (d->Ho & 1) || (d->Wo & 1) || (d->epilogue != YOLO_EPI_BIAS && d->epilogue != YOLO_EPI_BIAS_LRELU)))
@@ -477,6 +595,8 @@ YOLO_API int yolo_igemm(const yolo_igemm_desc *d, const void *in, const void *w,
         if (!bk64) return fail(YOLO_E_UNSUPPORTED, "yolo_igemm: blocked weights need tap_len %% 64 == 0");
         return p.M <= 64 ? launch<128, 64, 64, 2, 2, 2, MFMA_16x16x32>(p, splits, s) : launch<128, 128, 64, 2, 2, 2, MFMA_16x16x32>(p, splits, s);
     }
+    if (force == 12) return launch<256, 256, 32, 2, 4, 4, MFMA_16x16x32_STAGGER>(p, splits, s);
+    if (force == 13) return launch<256, 128, 32, 4, 2, 4, MFMA_16x16x32_STAGGER>(p, splits, s);
     if (!bk64) {
         if (force == 7) return launch<64, 128, 32, 2, 2, 3>(p, splits, s);
         if (force == 9) return launch<64, 128, 32, 2, 2, 4>(p, splits, s);
@@ -495,6 +615,7 @@ YOLO_API int yolo_igemm(const yolo_igemm_desc *d, const void *in, const void *w,
     if (force == 4) return launch<64, 128, 64, 2, 2, 2>(p, splits, s);
     if (force == 5) return launch<128, 128, 64, 2, 2, 2, MFMA_16x16x32>(p, splits, s);
     if (force == 6) return launch<256, 128, 64, 4, 2, 3, MFMA_16x16x32>(p, splits, s);
+    if (force == 11) return launch<256, 128, 64, 4, 2, 3, MFMA_16x16x32_STAGGER>(p, splits, s);
     if (p.M <= 64) return small_co ? launch<64, 64, 64, 2, 2, 2, MFMA_16x16x32>(p, splits, s) : launch<128, 64, 64, 2, 2, 2, MFMA_16x16x32>(p, splits, s);
     if (small_co) return launch<64, 128, 64, 2, 2, 2, MFMA_16x16x32>(p, splits, s);
     // (the 256x128 8-wave 3-stage configuration is built and tested but measured slower than 128x128

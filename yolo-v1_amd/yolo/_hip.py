@@ -35,6 +35,7 @@ class IgemmDesc(ctypes.Structure):
         ("aux_row_stride", ctypes.c_int32), ("aux_px_stride", ctypes.c_int32), ("aux_off", ctypes.c_int32),
         ("pool2", ctypes.c_int32),
         ("w_blocked", ctypes.c_int32),
+        ("tile_order", ctypes.c_int32),
         ("tile_hint", ctypes.c_int32),
     ]
 
