@@ -8,14 +8,14 @@ import csv, json, sys, collections
 d = sys.argv[1]
 tot = {}
 n = {}
+LAST = int(sys.argv[2]) if len(sys.argv) > 2 else 156   # igemm launches of the timed steps + roofline pass (2 x 3 x 26);
+                                                         # everything earlier is warm-up / tile autotuning
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
-    s = 0.0
-    k = 0
-    for r in csv.DictReader(open(f"{d}/pmc_{c}_counter_collection.csv")):
-        if "igemm_kernel" in r["Kernel_Name"] and r["Counter_Name"] == c:
-            s += float(r["Counter_Value"])
-            k += 1
-    tot[c], n[c] = s, k
+    rows = [(int(r["Dispatch_Id"]), float(r["Counter_Value"])) for r in csv.DictReader(open(f"{d}/pmc_{c}_counter_collection.csv"))
+            if "igemm_kernel" in r["Kernel_Name"] and r["Counter_Name"] == c]
+    rows.sort()
+    rows = rows[-LAST:]
+    tot[c], n[c] = sum(v for _, v in rows), len(rows)
 launches = n["FETCH_SIZE"]
 fetch = 2.0 * tot["FETCH_SIZE"] * 1024
 write = tot["WRITE_SIZE"] * 1024

@@ -64,41 +64,55 @@ class _timed:
 AUTOTUNE = True
 _TUNE_CANDIDATES = (5, 11, 12, 3, 4)      # 128x128 | 256x128 staggered | 256x256 staggered | 128x64 | 64x128
 _TUNED: dict = {}
+_FLUSH = None
+
+
+def _flush_caches(dev):
+    """evict L2 / Infinity Cache between tuning runs (512 MiB write): in the network every layer meets its
+    weights cold, which is what decides e.g. the tile order of the 1024-channel layers"""
+    global _FLUSH
+    if _FLUSH is None or _FLUSH.device != dev:
+        _FLUSH = torch.empty(512 << 20, dtype=torch.uint8, device=dev)
+    _FLUSH.fill_(1)
 
 
 def igemm_call(d: IgemmDesc, inp, w, bias, aux, out, st, what: str):
-    """yolo_igemm with the cached / autotuned tile configuration (only for plain, idempotent launches)."""
+    """yolo_igemm with the cached / autotuned (tile configuration, tile order) -- only for plain, idempotent launches."""
     L_ = lib()
-    tunable = (AUTOTUNE and TILE_HINT == 0 and d.split_k <= 1 and not d.w_blocked and d.tap_len % 64 == 0
-               and d.N * d.Ho * d.Wo >= 2048 and TIMERS is None)
-    if not tunable:
-        if d.tile_hint == 0 and TILE_HINT == 0 and d.split_k <= 1 and not d.w_blocked:
-            d.tile_hint = _TUNED.get(_tune_key(d), 0)
+    plain = TILE_HINT == 0 and d.split_k <= 1 and not d.w_blocked and d.tap_len % 64 == 0
+    if not plain:
+        d.tile_hint = TILE_HINT
         check(L_.yolo_igemm(ctypes.byref(d), inp, w, bias, aux, out, st), what)
         return
     key = _tune_key(d)
     best = _TUNED.get(key)
-    if best is None:
+    if best is None and AUTOTUNE and TIMERS is None and d.N * d.Ho * d.Wo >= 2048:
+        dev = torch.device("cuda", torch.cuda.current_device())
         cands = [c for c in _TUNE_CANDIDATES if not (d.pool2 and c in (3, 12))]
+        orders = (1, 2) if (d.Cout * d.KH * d.KW * d.tap_len * 2 > (4 << 20) and d.Cout >= 1024) else (1,)
         times = {}
         for c in cands:
-            d.tile_hint = c
-            try:
-                check(L_.yolo_igemm(ctypes.byref(d), inp, w, bias, aux, out, st), what)
-                ts = []
-                for _ in range(3):
-                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                    e0.record()
+            for o in orders:
+                d.tile_hint, d.tile_order = c, o
+                try:
                     check(L_.yolo_igemm(ctypes.byref(d), inp, w, bias, aux, out, st), what)
-                    e1.record()
-                    e1.synchronize()
-                    ts.append(e0.elapsed_time(e1))
-                times[c] = min(ts)
-            except RuntimeError:
-                continue
-        best = min(times, key=times.get) if times else 0
+                    ts = []
+                    for _ in range(3):
+                        _flush_caches(dev)
+                        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                        e0.record()
+                        check(L_.yolo_igemm(ctypes.byref(d), inp, w, bias, aux, out, st), what)
+                        e1.record()
+                        e1.synchronize()
+                        ts.append(e0.elapsed_time(e1))
+                    times[(c, o)] = min(ts)
+                except RuntimeError:
+                    continue
+        best = min(times, key=times.get) if times else (0, 0)
         _TUNED[key] = best
-    d.tile_hint = best
+    if best is None:
+        best = (0, 0)
+    d.tile_hint, d.tile_order = best
     check(L_.yolo_igemm(ctypes.byref(d), inp, w, bias, aux, out, st), what)
 
 
