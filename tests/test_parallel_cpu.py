@@ -80,3 +80,52 @@ def test_shard_batch():
     assert [shard_batch(512, r, 8) for r in (0, 7)] == [slice(0, 64), slice(448, 512)]
     with pytest.raises(ValueError):
         shard_batch(10, 0, 4)
+
+
+class _FakePlan:
+    """stands in for engine.Plan on the CPU: an arena plus the two callbacks"""
+
+    def __init__(self, n):
+        self.arena = torch.zeros(n)
+        self.on_grad_ready = None
+        self.on_backward_done = None
+
+
+def _overlap_worker(rank, world, port, q):
+    for p in (ROOT, os.path.join(ROOT, "yolo-v1_amd")):
+        sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from yolo.parallel import OverlappedGradAllReduce
+    plan = _FakePlan(1000)
+    ar = OverlappedGradAllReduce(plan, "cpu", bucket_bytes=4 * 300)
+    out = []
+    for step in range(2):
+        plan.arena.copy_(torch.arange(1000, dtype=torch.float32) * (rank + 1 + step))
+        for lo, hi in ((0, 100), (100, 450), (450, 700), (700, 900)):       # layers finishing in arena order
+            plan.on_grad_ready(lo, hi)
+        plan.on_backward_done()                                              # tail 900..1000 = bias region
+        ar.finish()
+        out.append(plan.arena.numpy().copy())
+    q.put((rank, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_overlapped_bucket_allreduce_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_overlap_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in procs], key=lambda r: r[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    base = torch.arange(1000, dtype=torch.float32).numpy()
+    for step in range(2):
+        want = base * ((1 + step) + (2 + step)) / 2          # mean over the two ranks
+        for r in res:
+            assert (abs(r[1][step] - want) < 1e-3).all()

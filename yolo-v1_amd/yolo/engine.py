@@ -192,6 +192,47 @@ class Plan:
         self._ws: dict[tuple, list] = {}
         self.debug_keep = False      # tests: keep the last workspace (activations + gradients) for inspection
         self.last = None
+        # optional persistent gradient arena (data-parallel training): one flat fp32 buffer holding every
+        # parameter gradient in the order backward PRODUCES them (last layer first), so that finished
+        # gradients form a growing contiguous prefix that can be all-reduced while backward continues
+        self.arena = None
+        self.arena_views: dict[int, tuple] = {}
+        self.on_grad_ready = None    # callback(lo, hi): arena[lo:hi] (elements) is final
+        self.on_backward_done = None
+
+    def attach_grad_arena(self, device) -> torch.Tensor:
+        """Allocate the gradient arena; backward then writes gradients into it, assigns ``p.grad`` views and
+        returns no gradients to autograd (gradients are OVERWRITTEN each backward: no accumulation)."""
+        order = [li for li in reversed(range(len(self.layers))) if self.layers[li].kind in ("conv", "fc")]
+        off = 0
+        wv, bv = {}, {}
+        for li in order:                          # every view starts on a 256-B boundary (float4 kernels)
+            n = self.layers[li].weight.numel()
+            wv[li] = (off, off + n, _round_up(off + n, 64))
+            off = _round_up(off + n, 64)
+        self._arena_w_end = off
+        for li in order:
+            n = self.layers[li].bias.numel()
+            bv[li] = (off, off + n)
+            off = _round_up(off + n, 64)
+        self.arena = torch.zeros(off, dtype=torch.float32, device=device)
+        self.arena_views = {li: (self.arena[wv[li][0]:wv[li][1]].view_as(self.layers[li].weight),
+                                 self.arena[bv[li][0]:bv[li][1]].view_as(self.layers[li].bias), wv[li][0], wv[li][2])
+                            for li in order}
+        return self.arena
+
+    def _grad_tensors(self, li: int, dev):
+        """(dw, db) destination for layer li: arena views or fresh tensors; db is zero-filled."""
+        L = self.layers[li]
+        if self.arena is not None:
+            dw, db, _, _ = self.arena_views[li]
+            return dw, db
+        return torch.empty_like(L.weight, dtype=torch.float32), torch.zeros_like(L.bias, dtype=torch.float32)
+
+    def _layer_done(self, li: int):
+        if self.arena is not None and self.on_grad_ready is not None:
+            _, _, a, b = self.arena_views[li]
+            self.on_grad_ready(a, b)
 
     # ------------------------------------------------------------------ construction helpers
     @staticmethod
@@ -460,6 +501,8 @@ class Plan:
         L_ = lib()
         st = stream()
         key, ws, fc_saved, N, dev = saved
+        if self.arena is not None:
+            self.arena[self._arena_w_end:].zero_()      # bias gradients are accumulated with atomics
         grads: dict[int, tuple] = {}
         nl = len(self.layers)
         gout = gout.detach()
@@ -501,12 +544,12 @@ class Plan:
                 check(L_.yolo_scale_rows_to_bf16(ptr(g_flat), ptr(mask), (1.0 / (1.0 - L.dropout)) if mask is not None else 1.0,
                                                  ptr(y_act) if (L.lrelu and not last) else None, self.SLOPE, N, L.Cout, ldg, ptr(gb), st), "scale_rows")
                 # weight / bias gradient, native [O][K] layout
-                dw = torch.empty_like(L.weight, dtype=torch.float32)
-                db = torch.zeros_like(L.bias, dtype=torch.float32)
+                dw, db = self._grad_tensors(li, dev)
                 wd = WgradDesc(N, ldg, L.Cin, L.Cout, L.Cin, 1, 1, 0, 0, 1, 0)
                 with _timed(f"fc{li}.wgrad", "wgrad", 2.0 * N * L.Cout * L.Cin):
                     check(L_.yolo_wgrad(ctypes.byref(wd), ptr(xin), ptr(gb), ptr(dw), ptr(db), st), f"wgrad fc{li}")
                 grads[li] = (dw, db)
+                self._layer_done(li)
                 # data gradient -> fp32 (N, K)
                 need_prev = li > 0 or need_gx
                 if need_prev:
@@ -561,8 +604,7 @@ class Plan:
                 g = g_act  # dZ of this layer, flat-geometry buffer
                 xin = input_of(li)
                 # ---- weight + bias gradient
-                db = torch.zeros_like(L.bias, dtype=torch.float32)
-                dw = torch.empty_like(L.weight, dtype=torch.float32)
+                dw, db = self._grad_tensors(li, dev)
                 if L.first:
                     xcol = ws["misc"].get("xcol")
                     if xcol is None:
@@ -584,6 +626,7 @@ class Plan:
                         check(L_.yolo_wgrad(ctypes.byref(wd), xin.p, g.p, ptr(dwp), ptr(db), st), f"wgrad conv{li}")
                     check(L_.yolo_unpack_conv_wgrad(ptr(dwp), L.Cout, L.Cin, L.K, L.K, L.Cin, L.K, ptr(dw), 0, st), "unpack")
                 grads[li] = (dw, db)
+                self._layer_done(li)
                 # ---- data gradient
                 if li == 0:
                     gx = None
@@ -595,6 +638,16 @@ class Plan:
                         self.last = (ws, fc_saved)
                     else:
                         self._release(key, ws)
+                    if self.arena is not None:
+                        if self.on_backward_done is not None:
+                            self.on_backward_done()
+                        for i in grads:          # hand the views to the optimizer without going through autograd
+                            L2 = self.layers[i]
+                            if L2.weight.grad is not grads[i][0]:
+                                L2.weight.grad = grads[i][0]
+                            if L2.bias.grad is not grads[i][1]:
+                                L2.bias.grad = grads[i][1]
+                        return gx, [None] * (2 * len(grads))
                     return gx, [grads[i][j] for i in sorted(grads) for j in (0, 1)]
                 _, wdg = self._pack(li, True)
                 prev = self.layers[li - 1]

@@ -61,3 +61,55 @@ def shard_batch(n_global: int, rank: int, world: int) -> slice:
         raise ValueError(f"global batch {n_global} does not divide over {world} ranks")
     per = n_global // world
     return slice(rank * per, (rank + 1) * per)
+
+
+class OverlappedGradAllReduce:
+    """Gradient averaging that runs WHILE backward is still producing gradients.
+
+    Works on an engine.Plan with a gradient arena (``plan.attach_grad_arena``): gradients land in one flat
+    buffer in the order backward produces them, so finished layers form a contiguous, growing prefix.  Every
+    time ``bucket_bytes`` more are final (the 822 MB FC1 gradient is the very first bucket) an asynchronous
+    all-reduce of that slice is enqueued; RCCL runs it on its own stream behind the kernels already queued
+    and beside the rest of the conv backward.  ``finish()`` (call it between ``backward()`` and the
+    optimizer) reduces the tail + the bias region and waits.  xGMI is point-to-point, so buckets are
+    large (default 64 MB) and few."""
+
+    def __init__(self, plan, device, bucket_bytes: int = 64 << 20, group=None):
+        self.plan = plan
+        self.group = group
+        self.bucket = max(1, bucket_bytes // 4)
+        self.arena = plan.arena if plan.arena is not None else plan.attach_grad_arena(device)
+        plan.on_grad_ready = self._ready
+        plan.on_backward_done = self._backward_done
+        self._sent = 0
+        self._final = 0
+        self._handles = []
+        self._avg = dist.get_backend(group) == "nccl"     # RCCL has ReduceOp.AVG; gloo does not
+
+    def _reduce(self, lo: int, hi: int):
+        if hi > lo:
+            op = dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM
+            self._handles.append(dist.all_reduce(self.arena[lo:hi], op=op, group=self.group, async_op=True))
+
+    def _ready(self, lo: int, hi: int):
+        # layers complete in arena order, so [0, hi) is final
+        self._final = max(self._final, hi)
+        if self._final - self._sent >= self.bucket:
+            self._reduce(self._sent, self._final)
+            self._sent = self._final
+
+    def _backward_done(self):
+        self._reduce(self._sent, self.arena.numel())      # remaining weights + the whole bias region
+        self._sent = self.arena.numel()
+
+    def finish(self) -> None:
+        for h in self._handles:
+            h.wait()
+        self._handles = []
+        if not self._avg:
+            self.arena.mul_(1.0 / dist.get_world_size(self.group))
+        self._sent = 0
+        self._final = 0
+
+    # same entry point as GradAllReduce, so training loops can use either
+    all_reduce_mean = finish
