@@ -216,6 +216,23 @@ int yolo_pack_fc_weight_blocked(const float *w, int O, long K, void *w_panels_bf
 /* packed fp32 gradient [Cout][KH][KWp][Cinp] -> OIHW fp32 (accumulate=0: overwrite, 1: add). */
 int yolo_unpack_conv_wgrad(const float *dw_packed, int Cout, int Cin, int KH, int KW, int Cinp, int KWp,
                            float *dw_oihw, int accumulate, yolo_stream_t stream);
+/* Whole-model forms of the two calls above: every conv layer of the model in ONE launch (LDS-tiled,
+ * all HBM accesses in runs of >= 128 B).  Layers need Cout % 64 == 0 (unpack: % 4), Cin % 64 == 0,
+ * KH*KW <= 9 and no padding (Cinp = Cin, KWp = KW); either output of a pack item may be NULL. */
+#define YOLO_PACK_MAX 32
+typedef struct yolo_conv_pack_item {
+    const float *w;            /* OIHW fp32 */
+    void *w_fwd_bf16;          /* [Cout][KH][KW][Cin] */
+    void *w_dgrad_bf16;        /* [Cin][KH][KW][Cout], taps flipped */
+    int Cout, Cin, KH, KW;
+} yolo_conv_pack_item;
+typedef struct yolo_conv_unpack_item {
+    const float *dw_packed;    /* [Cout][KH][KW][Cin] fp32 */
+    float *dw_oihw;
+    int Cout, Cin, KH, KW;
+} yolo_conv_unpack_item;
+int yolo_pack_conv_weights_multi(const yolo_conv_pack_item *items, int count, yolo_stream_t stream);
+int yolo_unpack_conv_wgrads_multi(const yolo_conv_unpack_item *items, int count, yolo_stream_t stream);
 /* Row-segment unfold for the 7x7/stride-2 first layer's WEIGHT GRADIENT only (Cin=3 gives no
  * channel-contiguous K axis): xcol[n][oy+h][ox+h][ky*seg + j] = x[n][oy*stride+ky][(ox*stride)*px + j],
  * written in the zero-haloed geometry of the layer's output so that yolo_wgrad's flat indexing
@@ -225,6 +242,14 @@ int yolo_im2col_rows(const void *x_bf16, long x_img_stride, int x_row_stride, in
 /* fp32 [R][Ccols] -> bf16 transposed y[c*ld + r] (ld >= R; columns R..ld-1 are not written: the
  * caller zero-fills once).  Data-gradient operand of a Linear layer ([K][O] from [O][K]). */
 int yolo_transpose_f32_to_bf16(const float *x, int R, int Ccols, void *y_bf16, int ld, yolo_stream_t stream);
+/* bf16 [R][ldx] -> bf16 transposed y[c*ldy + r] (columns R..ldy-1 of y are not written). */
+int yolo_transpose_bf16(const void *x_bf16, int R, int Ccols, int ldx, void *y_bf16, int ldy, yolo_stream_t stream);
+/* Data-gradient of the Linear layer behind nn.Flatten (models.py:240-241), computed TRANSPOSED by
+ * yolo_wgrad -- dxT[k][n] = sum_o W[o][k] * g[n][o] with the forward bf16 copy of W as the "dy" operand, so
+ * that no [K][O] transposed copy of the 205 M-element weight is ever written -- and finished here:
+ * k = c*H*W + h*W + w  ->  zero-haloed NHWC bf16 gradient, times LeakyReLU'(y_act) (y_act NULL: none). */
+int yolo_fc_dgrad_to_nhwc(const float *dxT, int N, int C, int H, int W, int halo, const void *y_act_bf16,
+                          float slope, void *g_bf16, yolo_stream_t stream);
 int yolo_cast_f32_to_bf16(const float *x, long n, void *y_bf16, yolo_stream_t stream);
 int yolo_cast_bf16_to_f32(const void *x_bf16, long n, float *y, yolo_stream_t stream);
 /* y = lrelu(x + bias[col]) over [R][Ccols] fp32, bf16 and/or fp32 outputs (finishes a split-K Linear). */
@@ -253,6 +278,21 @@ int yolo_sumsq_f32(const float *g, long n, double *acc, yolo_stream_t stream);
 int yolo_adam_step(float *p, const float *g, float *exp_avg, float *exp_avg_sq, long n, float lr, float beta1,
                    float beta2, float eps, float weight_decay, long step, const double *norm_sq,
                    float max_norm, void *p_bf16, yolo_stream_t stream);
+/* Multi-tensor forms: ONE launch for a whole parameter list (the reference's optimizer is torch's
+ * multi-tensor `_foreach` Adam; 48 of this model's 52 tensors are too small to fill the chip alone).
+ * Tables are host arrays; they are copied into the kernel arguments, YOLO_MT_MAX tensors per launch.
+ * All tensors of one yolo_adam_step_multi call share `step` and the hyper-parameters. */
+#define YOLO_MT_MAX 48
+typedef struct yolo_adam_tensor {
+    float *p;            /* parameter, updated in place */
+    const float *g;      /* gradient */
+    float *m, *v;        /* exp_avg, exp_avg_sq */
+    void *p_bf16;        /* optional bf16 shadow of p in the same layout (NULL: none) */
+    long n;              /* elements */
+} yolo_adam_tensor;
+int yolo_sumsq_f32_multi(const float *const *g, const long *n, int count, double *acc, yolo_stream_t stream);
+int yolo_adam_step_multi(const yolo_adam_tensor *t, int count, float lr, float beta1, float beta2, float eps,
+                         float weight_decay, long step, const double *norm_sq, float max_norm, yolo_stream_t stream);
 /* g *= min(1, max_norm / (sqrt(*norm_sq) + 1e-6))  (stand-alone clip_grad_norm_ for other optimizers). */
 int yolo_clip_scale_f32(float *g, long n, const double *norm_sq, float max_norm, yolo_stream_t stream);
 

@@ -210,6 +210,47 @@ def test_layout_roundtrip():
     assert v[:, 0].abs().sum() == 0 and v[:, -1].abs().sum() == 0 and v[:, :, 0].abs().sum() == 0 and v[:, :, -1].abs().sum() == 0
 
 
+def test_multi_layer_pack_and_unpack_are_exact():
+    """yolo_pack_conv_weights_multi / yolo_unpack_conv_wgrads_multi == pure index permutations of the OIHW tensor."""
+    import ctypes
+    from yolo._hip import ConvPackItem, ConvUnpackItem, check, lib, stream
+    torch.manual_seed(3)
+    shapes = [(64, 64, 3), (128, 192, 1), (192, 64, 3), (256, 128, 3), (64, 128, 1)]
+    ws = [torch.randn(co, ci, k, k, device="cuda") for co, ci, k in shapes]
+    wf = [torch.empty(co, k, k, ci, dtype=torch.bfloat16, device="cuda") for co, ci, k in shapes]
+    wd = [torch.empty(ci, k, k, co, dtype=torch.bfloat16, device="cuda") for co, ci, k in shapes]
+    items = [ConvPackItem(w.data_ptr(), f.data_ptr(), d.data_ptr() if i != 1 else None, co, ci, k, k)
+             for i, (w, f, d, (co, ci, k)) in enumerate(zip(ws, wf, wd, shapes))]
+    check(lib().yolo_pack_conv_weights_multi((ConvPackItem * len(items))(*items), len(items), stream()))
+    for i, (w, f, d) in enumerate(zip(ws, wf, wd)):
+        assert torch.equal(f, w.permute(0, 2, 3, 1).to(torch.bfloat16)), f"forward operand {i}"
+        if i != 1:
+            assert torch.equal(d, w.flip(2, 3).permute(1, 2, 3, 0).to(torch.bfloat16)), f"data-gradient operand {i}"
+    packed = [torch.randn(co, k, k, ci, device="cuda") for co, ci, k in shapes]
+    out = [torch.empty(co, ci, k, k, device="cuda") for co, ci, k in shapes]
+    it2 = [ConvUnpackItem(a.data_ptr(), b.data_ptr(), co, ci, k, k) for a, b, (co, ci, k) in zip(packed, out, shapes)]
+    check(lib().yolo_unpack_conv_wgrads_multi((ConvUnpackItem * len(it2))(*it2), len(it2), stream()))
+    for a, b in zip(packed, out):
+        assert torch.equal(b, a.permute(0, 3, 1, 2))
+    # rejected, not silently mis-packed
+    bad = ConvPackItem(ws[0].data_ptr(), wf[0].data_ptr(), None, 60, 64, 3, 3)
+    assert lib().yolo_pack_conv_weights_multi((ConvPackItem * 1)(bad), 1, stream()) != 0
+
+
+def test_fc_dgrad_behind_flatten_matches_cpu():
+    """Linear behind nn.Flatten: the data gradient goes through yolo_wgrad (transposed product) + yolo_fc_dgrad_to_nhwc."""
+    torch.manual_seed(5)
+    mods = nn.Sequential(nn.Conv2d(32, 64, 3, padding=1), nn.LeakyReLU(0.1), nn.Flatten(), nn.Linear(64 * 5 * 6, 192), nn.LeakyReLU(0.1),
+                         nn.Dropout(0.5), nn.Linear(192, 70)).eval()
+    x = torch.randn(5, 32, 5, 6)
+    gy = torch.randn(5, 70)
+    yc, yg, gc, gg = _run_both(mods, x, gy)
+    _close(yg, yc, 2.0, "forward")
+    names = ["dx"] + [n for n, _ in mods.named_parameters()]
+    for n, a, b in zip(names, gg, gc):
+        _close(a, b, 3.0, n, frac=0.01)
+
+
 @pytest.mark.parametrize("hint", [1, 2, 3, 4, 5, 6, 11, 12, 13])
 def test_every_tile_configuration(hint):
     """the same 3x3 / 1x1 chain through each yolo_igemm tile configuration (128x128, 256x128 8-wave

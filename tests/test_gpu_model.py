@@ -173,7 +173,7 @@ def test_hip_adam_matches_torch_adam():
     """yolo.optim.Adam(max_grad_norm=10) == clip_grad_norm_(10) + torch.optim.Adam, three steps."""
     from yolo.optim import Adam, clip_grad_norm_
     torch.manual_seed(0)
-    shapes = [(1000, 37), (4096,), (3, 3, 3, 5), (1 << 20,)]
+    shapes = [(1000, 37), (4096,), (3, 3, 3, 5), (1 << 20,)] + [(17 + i,) for i in range(60)]   # > YOLO_MT_MAX tensors: two launches
     pa = [torch.randn(s, device="cuda").requires_grad_(True) for s in shapes]
     pb = [p.detach().clone().requires_grad_(True) for p in pa]
     oa = Adam(pa, lr=1e-3, weight_decay=5e-4, max_grad_norm=10.0)
@@ -199,6 +199,46 @@ def test_hip_adam_matches_torch_adam():
         torch.testing.assert_close(p.grad, q.grad, rtol=1e-5, atol=1e-7)
     # state_dict is interchangeable with torch.optim.Adam
     ob.load_state_dict(oa.state_dict())
+
+
+def test_adam_refreshes_linear_bf16_operands():
+    """Adam.attach_plan: the bf16 forward operand of every Linear is rewritten by the optimizer pass itself and the
+    engine's cache accepts it (no re-cast); conv operands are re-packed by the next forward.  Two steps vs torch."""
+    import copy
+    import torch.nn as nn
+    from yolo import engine
+    from yolo.optim import Adam
+    torch.manual_seed(2)
+    mods = nn.Sequential(nn.Conv2d(64, 64, 3, padding=1), nn.LeakyReLU(0.1), nn.Flatten(), nn.Linear(64 * 4 * 4, 128), nn.LeakyReLU(0.1),
+                         nn.Dropout(0.5), nn.Linear(128, 30)).cuda().eval()
+    ref = copy.deepcopy(mods)
+    plan = engine.Plan.from_modules(list(mods), 64, False)
+    oa = Adam(mods.parameters(), lr=1e-2, max_grad_norm=10.0)
+    oa.attach_plan(plan)
+    ob = torch.optim.Adam(ref.parameters(), lr=1e-2)
+    x = torch.randn(4, 64, 4, 4, device="cuda")
+    fc = [li for li, L in enumerate(plan.layers) if L.kind == "fc"]
+    for it in range(2):
+        oa.zero_grad(set_to_none=True)
+        engine.run_plan(plan, x, False).square().mean().backward()
+        for p, q in zip(mods.parameters(), ref.parameters()):
+            q.grad = p.grad.clone()
+        torch.nn.utils.clip_grad_norm_(ref.parameters(), 10.0)
+        ob.step()
+        oa.step()
+        for li in fc:
+            L = plan.layers[li]
+            key, wf = plan._pf[li]
+            assert key == plan._wkey(L.weight), "engine cache must accept the optimizer's shadow"
+            assert torch.equal(wf.view(-1), L.weight.detach().to(torch.bfloat16).view(-1))
+        for p, q in zip(mods.parameters(), ref.parameters()):
+            torch.testing.assert_close(p, q, rtol=2e-5, atol=2e-6)
+    # the refreshed operands are what the next forward computes with
+    with torch.no_grad():
+        y1 = engine.run_plan(plan, x, False)
+        plan._pf.clear(); plan._pd.clear()
+        y2 = engine.run_plan(plan, x, False)
+    assert torch.equal(y1, y2)
 
 
 def test_detection_head_on_the_engine():

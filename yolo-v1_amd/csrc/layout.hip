@@ -2,6 +2,8 @@
 // (NCHW activations, OIHW / [O][K] weights: the state_dict contract of SURVEY.md 8b) and the
 // network's internal format (zero-haloed NHWC bf16 activations, K-contiguous bf16 weight panels).
 // All HBM-bound; every kernel moves 8-16 B per lane on its contiguous side.
+#include <algorithm>
+
 #include "common.h"
 
 namespace yolo {
@@ -112,6 +114,107 @@ __global__ void unpack_conv_wgrad_kernel(const float *__restrict__ dwp, int Cout
     dw[idx] = accumulate ? dw[idx] + v : v;
 }
 
+// ---- all conv layers of a model in ONE launch ---------------------------------------------------
+// The per-layer kernels above index element by element (stride-KH*KW gathers) and a 24-layer model
+// needs 48 + 24 launches of them per training step, most too small to fill the chip.  These go
+// through LDS tiles instead -- every HBM access is a run of >= 128 B -- and take the whole layer list
+// in the kernel arguments.
+constexpr int PK_T = 64;          // co x ci tile edge
+struct PackItem {
+    const float *w;
+    bf16_t *wf, *wd;
+    int Cout, Cin, KK;            // KK = KH*KW
+    int n_ci_tiles;
+    int first;                    // first workgroup of this layer
+};
+struct PackTable {
+    PackItem it[YOLO_PACK_MAX];
+    int count, total;
+};
+
+__global__ void __launch_bounds__(256) pack_conv_multi_kernel(const PackTable tab)
+{
+    extern __shared__ __attribute__((aligned(16))) bf16_t tile[];  // [64 co][64*KK + 4]
+    int li = 0;
+    while (li + 1 < tab.count && tab.it[li + 1].first <= (int)blockIdx.x) ++li;
+    const PackItem &L = tab.it[li];
+    const int b = blockIdx.x - L.first;
+    const int ci0 = (b % L.n_ci_tiles) * PK_T, co0 = (b / L.n_ci_tiles) * PK_T;
+    const int KK = L.KK, row = PK_T * KK, pitch = row + 4;
+    // load: 64 rows of 64*KK contiguous floats
+    const int q_per_row = row / 4;
+    for (int idx = threadIdx.x; idx < PK_T * q_per_row; idx += 256) {
+        const int r = idx / q_per_row, j = idx - r * q_per_row;
+        const float4 v = *reinterpret_cast<const float4 *>(L.w + ((long)(co0 + r) * L.Cin + ci0) * KK + 4 * j);
+        uint2 o;
+        o.x = (unsigned)f32_to_bf16(v.x) | ((unsigned)f32_to_bf16(v.y) << 16);
+        o.y = (unsigned)f32_to_bf16(v.z) | ((unsigned)f32_to_bf16(v.w) << 16);
+        *reinterpret_cast<uint2 *>(tile + r * pitch + 4 * j) = o;
+    }
+    __syncthreads();
+    // forward operand wf[co][tap][ci]: 8 ci (16 B) per lane, 128-B runs
+    if (L.wf) {
+        for (int idx = threadIdx.x; idx < PK_T * KK * 8; idx += 256) {
+            const int c8 = idx & 7, t = (idx >> 3) % KK, r = (idx >> 3) / KK;
+            const bf16_t *src = tile + r * pitch + (c8 * 8) * KK + t;
+            unsigned short e[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) e[k] = src[k * KK];
+            uint4 o = {(unsigned)e[0] | ((unsigned)e[1] << 16), (unsigned)e[2] | ((unsigned)e[3] << 16), (unsigned)e[4] | ((unsigned)e[5] << 16),
+                       (unsigned)e[6] | ((unsigned)e[7] << 16)};
+            *reinterpret_cast<uint4 *>(L.wf + ((long)(co0 + r) * KK + t) * L.Cin + ci0 + c8 * 8) = o;
+        }
+    }
+    // data-gradient operand wd[ci][KK-1-tap][co]: 8 co per lane
+    if (L.wd) {
+        for (int idx = threadIdx.x; idx < PK_T * KK * 8; idx += 256) {
+            const int c8 = idx & 7, t = (idx >> 3) % KK, ci = (idx >> 3) / KK;
+            const bf16_t *src = tile + (c8 * 8) * pitch + ci * KK + t;
+            unsigned short e[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) e[k] = src[k * pitch];
+            uint4 o = {(unsigned)e[0] | ((unsigned)e[1] << 16), (unsigned)e[2] | ((unsigned)e[3] << 16), (unsigned)e[4] | ((unsigned)e[5] << 16),
+                       (unsigned)e[6] | ((unsigned)e[7] << 16)};
+            *reinterpret_cast<uint4 *>(L.wd + ((long)(ci0 + ci) * KK + (KK - 1 - t)) * L.Cout + co0 + c8 * 8) = o;
+        }
+    }
+}
+
+struct UnpackItem {
+    const float *dwp;
+    float *dw;
+    int Cout, Cin, KK;
+    int n_ci_tiles;
+    int first;
+};
+struct UnpackTable {
+    UnpackItem it[YOLO_PACK_MAX];
+    int count, total;
+};
+constexpr int UP_CO = 4;  // output channels per workgroup
+
+// packed [co][tap][ci] fp32 -> OIHW [co][ci][tap]: workgroup = 4 co x 64 ci x all taps
+__global__ void __launch_bounds__(256) unpack_conv_multi_kernel(const UnpackTable tab)
+{
+    extern __shared__ __attribute__((aligned(16))) float ftile[];  // [4][KK][65]
+    int li = 0;
+    while (li + 1 < tab.count && tab.it[li + 1].first <= (int)blockIdx.x) ++li;
+    const UnpackItem &L = tab.it[li];
+    const int b = blockIdx.x - L.first;
+    const int ci0 = (b % L.n_ci_tiles) * PK_T, co0 = (b / L.n_ci_tiles) * UP_CO;
+    const int KK = L.KK;
+    for (int idx = threadIdx.x; idx < UP_CO * KK * PK_T; idx += 256) {
+        const int ci = idx & 63, t = (idx >> 6) % KK, c = (idx >> 6) / KK;
+        ftile[(c * KK + t) * 65 + ci] = L.dwp[((long)(co0 + c) * KK + t) * L.Cin + ci0 + ci];
+    }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < UP_CO * KK * PK_T; idx += 256) {
+        const int j = idx % (KK * PK_T), c = idx / (KK * PK_T);
+        const int ci = j / KK, t = j - ci * KK;
+        L.dw[((long)(co0 + c) * L.Cin + ci0) * KK + j] = ftile[(c * KK + t) * 65 + ci];
+    }
+}
+
 // ---- Linear weights ----------------------------------------------------------------------------
 // w[o][c*HW + hw] fp32 -> wf[o][hw*C + c] bf16.  One workgroup per (o, 64-channel slab): the slab
 // (64*HW contiguous floats) is read coalesced into LDS and written back as HW runs of 64 bf16.
@@ -179,6 +282,44 @@ __global__ void __launch_bounds__(256) transpose_bf16_kernel(const bf16_t *__res
 __global__ void __launch_bounds__(256) transpose_f32_bf16_kernel(const float *__restrict__ x, long R, long Cc, bf16_t *__restrict__ y, long ld)
 {
     transpose_tile(x, R, Cc, y, ld, [](float v) { return f32_to_bf16(v); });
+}
+
+// bf16 [R][ldx] -> bf16 [Cc][ldy] (small matrices: the batch-side operand of a Linear data-gradient)
+__global__ void __launch_bounds__(256) transpose_bf16_ld_kernel(const bf16_t *__restrict__ x, int R, int Cc, int ldx, bf16_t *__restrict__ y, int ldy)
+{
+    __shared__ bf16_t t[64][66];
+    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int k = ty; k < 64; k += 4)
+        if (r0 + k < R && c0 + tx < Cc) t[k][tx] = x[(long)(r0 + k) * ldx + c0 + tx];
+    __syncthreads();
+    for (int k = ty; k < 64; k += 4)
+        if (c0 + k < Cc && r0 + tx < R) y[(long)(c0 + k) * ldy + r0 + tx] = t[tx][k];
+}
+
+// Linear data-gradient, produced transposed by yolo_wgrad as dxT[k][n] (k = c*HW + hw, nn.Flatten order),
+// -> zero-haloed NHWC bf16 gradient g[n][h][w][c], times LeakyReLU'(y) of the conv in front of nn.Flatten
+__global__ void __launch_bounds__(256) fc_dgrad_to_nhwc_kernel(const float *__restrict__ dxT, int N, int C, int H, int W, int halo,
+                                                               const bf16_t *__restrict__ yact, float slope, bf16_t *__restrict__ g)
+{
+    __shared__ float t[64][65];
+    const int HW = H * W;
+    const int c0 = blockIdx.x * 64, hw = blockIdx.y, n0 = blockIdx.z * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int k = ty; k < 64; k += 4)
+        if (c0 + k < C && n0 + tx < N) t[k][tx] = dxT[((long)(c0 + k) * HW + hw) * N + n0 + tx];
+    __syncthreads();
+    const int h = hw / W, w = hw - h * W;
+    const int Hp = H + 2 * halo, Wp = W + 2 * halo;
+    for (int k = ty; k < 64; k += 4) {
+        const int n = n0 + k, c = c0 + tx;
+        if (n < N && c < C) {
+            const long o = (((long)n * Hp + h + halo) * Wp + w + halo) * C + c;
+            float v = t[tx][k];
+            if (yact && !(bf16_to_f32(yact[o]) > 0.0f)) v *= slope;
+            g[o] = f32_to_bf16(v);
+        }
+    }
 }
 
 // ---- first-layer weight-gradient operand: rows of KH x 32 input elements per output pixel -------
@@ -334,11 +475,93 @@ YOLO_API int yolo_unpack_conv_wgrad(const float *dwp, int Cout, int Cin, int KH,
     return check_launch("yolo_unpack_conv_wgrad");
 }
 
+YOLO_API int yolo_pack_conv_weights_multi(const yolo_conv_pack_item *items, int count, yolo_stream_t stream)
+{
+    if (!items || count < 0) return fail(YOLO_E_ARG, "yolo_pack_conv_weights_multi: bad argument");
+    for (int base = 0; base < count; base += YOLO_PACK_MAX) {
+        PackTable tab{};
+        int kmax = 1, blocks = 0;
+        const int n = std::min(YOLO_PACK_MAX, count - base);
+        for (int k = 0; k < n; ++k) {
+            const yolo_conv_pack_item &e = items[base + k];
+            if (!e.w || (!e.w_fwd_bf16 && !e.w_dgrad_bf16) || e.Cout <= 0 || e.Cin <= 0 || e.KH <= 0 || e.KW <= 0)
+                return fail(YOLO_E_ARG, "yolo_pack_conv_weights_multi: layer %d: bad descriptor", base + k);
+            if ((e.Cout % PK_T) || (e.Cin % PK_T) || e.KH * e.KW > 9)
+                return fail(YOLO_E_UNSUPPORTED, "yolo_pack_conv_weights_multi: layer %d: Cout, Cin must be multiples of 64 and KH*KW <= 9 (use yolo_pack_conv_weight)", base + k);
+            if (((uintptr_t)e.w | (uintptr_t)e.w_fwd_bf16 | (uintptr_t)e.w_dgrad_bf16) & 15)
+                return fail(YOLO_E_UNSUPPORTED, "yolo_pack_conv_weights_multi: layer %d: pointers must be 16-B aligned", base + k);
+            PackItem &t = tab.it[k];
+            t.w = e.w; t.wf = (bf16_t *)e.w_fwd_bf16; t.wd = (bf16_t *)e.w_dgrad_bf16;
+            t.Cout = e.Cout; t.Cin = e.Cin; t.KK = e.KH * e.KW;
+            t.n_ci_tiles = e.Cin / PK_T;
+            t.first = blocks;
+            blocks += t.n_ci_tiles * (e.Cout / PK_T);
+            kmax = std::max(kmax, t.KK);
+        }
+        tab.count = n; tab.total = blocks;
+        const size_t lds = (size_t)PK_T * (PK_T * kmax + 4) * sizeof(bf16_t);  // 74 KB for 3x3
+        static bool big_lds = false;
+        if (!big_lds) {
+            if (hipFuncSetAttribute((const void *)pack_conv_multi_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) != hipSuccess)
+                return fail(YOLO_E_UNSUPPORTED, "yolo_pack_conv_weights_multi: cannot reserve %zu B of LDS", lds);
+            big_lds = true;
+        }
+        hipLaunchKernelGGL(pack_conv_multi_kernel, dim3(blocks), dim3(256), lds, STRM(stream), tab);
+        if (int rc = check_launch("yolo_pack_conv_weights_multi")) return rc;
+    }
+    return 0;
+}
+
+YOLO_API int yolo_unpack_conv_wgrads_multi(const yolo_conv_unpack_item *items, int count, yolo_stream_t stream)
+{
+    if (!items || count < 0) return fail(YOLO_E_ARG, "yolo_unpack_conv_wgrads_multi: bad argument");
+    for (int base = 0; base < count; base += YOLO_PACK_MAX) {
+        UnpackTable tab{};
+        int kmax = 1, blocks = 0;
+        const int n = std::min(YOLO_PACK_MAX, count - base);
+        for (int k = 0; k < n; ++k) {
+            const yolo_conv_unpack_item &e = items[base + k];
+            if (!e.dw_packed || !e.dw_oihw || e.Cout <= 0 || e.Cin <= 0 || e.KH <= 0 || e.KW <= 0)
+                return fail(YOLO_E_ARG, "yolo_unpack_conv_wgrads_multi: layer %d: bad descriptor", base + k);
+            if ((e.Cout % UP_CO) || (e.Cin % PK_T) || e.KH * e.KW > 9)
+                return fail(YOLO_E_UNSUPPORTED, "yolo_unpack_conv_wgrads_multi: layer %d: Cout %% 4, Cin %% 64, KH*KW <= 9 required (use yolo_unpack_conv_wgrad)", base + k);
+            UnpackItem &t = tab.it[k];
+            t.dwp = e.dw_packed; t.dw = e.dw_oihw;
+            t.Cout = e.Cout; t.Cin = e.Cin; t.KK = e.KH * e.KW;
+            t.n_ci_tiles = e.Cin / PK_T;
+            t.first = blocks;
+            blocks += t.n_ci_tiles * (e.Cout / UP_CO);
+            kmax = std::max(kmax, t.KK);
+        }
+        tab.count = n; tab.total = blocks;
+        const size_t lds = (size_t)UP_CO * kmax * 65 * sizeof(float);
+        hipLaunchKernelGGL(unpack_conv_multi_kernel, dim3(blocks), dim3(256), lds, STRM(stream), tab);
+        if (int rc = check_launch("yolo_unpack_conv_wgrads_multi")) return rc;
+    }
+    return 0;
+}
+
 YOLO_API int yolo_transpose_f32_to_bf16(const float *x, int R, int Cc, void *y, int ld, yolo_stream_t stream)
 {
     if (!x || !y || R <= 0 || Cc <= 0 || ld < R) return fail(YOLO_E_ARG, "yolo_transpose_f32_to_bf16: bad argument");
     hipLaunchKernelGGL(transpose_f32_bf16_kernel, dim3(nblk(Cc, 64), nblk(R, 64)), dim3(256), 0, STRM(stream), x, (long)R, (long)Cc, (bf16_t *)y, (long)ld);
     return check_launch("yolo_transpose_f32_to_bf16");
+}
+
+YOLO_API int yolo_transpose_bf16(const void *x, int R, int Cc, int ldx, void *y, int ldy, yolo_stream_t stream)
+{
+    if (!x || !y || R <= 0 || Cc <= 0 || ldx < Cc || ldy < R) return fail(YOLO_E_ARG, "yolo_transpose_bf16: bad argument");
+    hipLaunchKernelGGL(transpose_bf16_ld_kernel, dim3(nblk(Cc, 64), nblk(R, 64)), dim3(256), 0, STRM(stream), (const bf16_t *)x, R, Cc, ldx, (bf16_t *)y, ldy);
+    return check_launch("yolo_transpose_bf16");
+}
+
+YOLO_API int yolo_fc_dgrad_to_nhwc(const float *dxT, int N, int C, int H, int W, int halo, const void *y_act, float slope, void *g, yolo_stream_t stream)
+{
+    if (!dxT || !g || N <= 0 || C <= 0 || H <= 0 || W <= 0 || halo < 0) return fail(YOLO_E_ARG, "yolo_fc_dgrad_to_nhwc: bad argument");
+    if ((long)H * W > 65535 || nblk(N, 64) > 65535) return fail(YOLO_E_UNSUPPORTED, "yolo_fc_dgrad_to_nhwc: H*W=%ld or N=%d too large", (long)H * W, N);
+    hipLaunchKernelGGL(fc_dgrad_to_nhwc_kernel, dim3(nblk(C, 64), H * W, nblk(N, 64)), dim3(256), 0, STRM(stream), dxT, N, C, H, W, halo, (const bf16_t *)y_act,
+                       slope, (bf16_t *)g);
+    return check_launch("yolo_fc_dgrad_to_nhwc");
 }
 
 YOLO_API int yolo_cast_f32_to_bf16(const float *x, long n, void *y, yolo_stream_t stream)

@@ -8,6 +8,11 @@
 //                    whole step needs no host synchronisation.  Optionally also writes bf16(p) (the
 //                    forward operand of Linear layers has the master's layout).
 // 16 B per lane on every stream (float4), grid-stride, <= 2048 workgroups.
+//
+// Multi-tensor forms (yolo_sumsq_f32_multi, yolo_adam_step_multi): the model has 52 parameter tensors,
+// 48 of them small; one launch per tensor leaves most of the chip idle for most of the step.  The
+// per-tensor table travels in the kernel arguments (<= YOLO_MT_MAX entries per launch), a workgroup
+// owns one MT_CHUNK-element slice of one tensor and finds it by scanning the table's chunk prefix.
 #include "common.h"
 
 namespace yolo {
@@ -81,6 +86,97 @@ __global__ void __launch_bounds__(256) adam_kernel(float *__restrict__ p, const 
     }
 }
 
+constexpr int MT_CHUNK = 8192;  // elements per workgroup: 256 lanes x float4 x 8
+
+struct SumsqTable {
+    const float *g[YOLO_MT_MAX];
+    long n[YOLO_MT_MAX];
+    int first[YOLO_MT_MAX + 1];   // first chunk (= workgroup) of every tensor
+    int count;
+};
+struct AdamTable {
+    yolo_adam_tensor t[YOLO_MT_MAX];
+    int first[YOLO_MT_MAX + 1];
+    int count;
+};
+
+__device__ __forceinline__ int find_tensor(const int *first, int count, int b)
+{
+    int i = 0;
+    while (i + 1 < count && first[i + 1] <= b) ++i;  // wave-uniform scalar scan of <= 48 entries
+    return i;
+}
+
+__global__ void __launch_bounds__(256) sumsq_multi_kernel(const SumsqTable tab, double *__restrict__ acc)
+{
+    const int ti = find_tensor(tab.first, tab.count, blockIdx.x);
+    const float *__restrict__ g = tab.g[ti];
+    const long n = tab.n[ti];
+    const long beg = (long)(blockIdx.x - tab.first[ti]) * MT_CHUNK;
+    const long end = min(n, beg + MT_CHUNK);
+    double s = 0.0;
+    for (long i = beg + threadIdx.x * 4; i < end; i += 1024) {
+        if (i + 4 <= end) {
+            const float4 v = *reinterpret_cast<const float4 *>(g + i);
+            s += (double)(v.x * v.x + v.y * v.y) + (double)(v.z * v.z + v.w * v.w);
+        } else {
+            for (long k = i; k < end; ++k) s += (double)(g[k] * g[k]);
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    __shared__ double part[4];
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(acc, part[0] + part[1] + part[2] + part[3]);
+}
+
+__global__ void __launch_bounds__(256) adam_multi_kernel(const AdamTable tab, float b1, float b2, float eps, float wd, float step_size, float inv_bc2_sqrt,
+                                                         const double *__restrict__ norm_sq, float max_norm)
+{
+    float clip = 1.0f;
+    if (norm_sq) {
+        const float total = (float)sqrt(*norm_sq);
+        const float c = max_norm / (total + 1e-6f);
+        clip = c < 1.0f ? c : 1.0f;
+    }
+    const int ti = find_tensor(tab.first, tab.count, blockIdx.x);
+    float *__restrict__ p = tab.t[ti].p;
+    const float *__restrict__ g = tab.t[ti].g;
+    float *__restrict__ m = tab.t[ti].m;
+    float *__restrict__ v = tab.t[ti].v;
+    bf16_t *__restrict__ pb = (bf16_t *)tab.t[ti].p_bf16;
+    const long n = tab.t[ti].n;
+    const long beg = (long)(blockIdx.x - tab.first[ti]) * MT_CHUNK;
+    const long end = min(n, beg + MT_CHUNK);
+    for (long i = beg + threadIdx.x * 4; i < end; i += 1024) {
+        if (i + 4 <= end) {
+            float4 pv = *reinterpret_cast<float4 *>(p + i);
+            const float4 gv = *reinterpret_cast<const float4 *>(g + i);
+            float4 mv = *reinterpret_cast<float4 *>(m + i), vv = *reinterpret_cast<float4 *>(v + i);
+            adam1(pv.x, gv.x, mv.x, vv.x, clip, wd, b1, b2, step_size, inv_bc2_sqrt, eps);
+            adam1(pv.y, gv.y, mv.y, vv.y, clip, wd, b1, b2, step_size, inv_bc2_sqrt, eps);
+            adam1(pv.z, gv.z, mv.z, vv.z, clip, wd, b1, b2, step_size, inv_bc2_sqrt, eps);
+            adam1(pv.w, gv.w, mv.w, vv.w, clip, wd, b1, b2, step_size, inv_bc2_sqrt, eps);
+            *reinterpret_cast<float4 *>(p + i) = pv;
+            *reinterpret_cast<float4 *>(m + i) = mv;
+            *reinterpret_cast<float4 *>(v + i) = vv;
+            if (pb) {
+                uint2 o;
+                o.x = (unsigned)f32_to_bf16(pv.x) | ((unsigned)f32_to_bf16(pv.y) << 16);
+                o.y = (unsigned)f32_to_bf16(pv.z) | ((unsigned)f32_to_bf16(pv.w) << 16);
+                *reinterpret_cast<uint2 *>(pb + i) = o;
+            }
+        } else {
+            for (long k = i; k < end; ++k) {
+                float pk = p[k], mk = m[k], vk = v[k];
+                adam1(pk, g[k], mk, vk, clip, wd, b1, b2, step_size, inv_bc2_sqrt, eps);
+                p[k] = pk; m[k] = mk; v[k] = vk;
+                if (pb) pb[k] = f32_to_bf16(pk);
+            }
+        }
+    }
+}
+
 __global__ void scale_by_clip_kernel(float *__restrict__ g, long n, const double *__restrict__ norm_sq, float max_norm)
 {
     const float total = (float)sqrt(*norm_sq);
@@ -123,6 +219,69 @@ YOLO_API int yolo_adam_step(float *p, const float *g, float *m, float *v, long n
     hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n, 8)), dim3(256), 0, STRM(stream), p, g, m, v, n, beta1, beta2, eps, weight_decay, step_size, inv_bc2_sqrt,
                        norm_sq, max_norm, (bf16_t *)p_bf16);
     return check_launch("yolo_adam_step");
+}
+
+YOLO_API int yolo_sumsq_f32_multi(const float *const *g, const long *n, int count, double *acc, yolo_stream_t stream)
+{
+    if (!g || !n || !acc || count < 0) return fail(YOLO_E_ARG, "yolo_sumsq_f32_multi: bad argument");
+    for (int base = 0; base < count;) {
+        SumsqTable tab{};
+        long chunks = 0;
+        int k = 0;
+        for (; base + k < count && k < YOLO_MT_MAX; ++k) {
+            const float *gp = g[base + k];
+            const long nn = n[base + k];
+            if (!gp || nn < 0) return fail(YOLO_E_ARG, "yolo_sumsq_f32_multi: tensor %d: null pointer or negative size", base + k);
+            if ((uintptr_t)gp & 15) return fail(YOLO_E_UNSUPPORTED, "yolo_sumsq_f32_multi: tensor %d is not 16-B aligned", base + k);
+            const long c = (nn + MT_CHUNK - 1) / MT_CHUNK;
+            if (chunks + c > 0x7fffffffL) break;
+            tab.g[k] = gp; tab.n[k] = nn; tab.first[k] = (int)chunks;
+            chunks += c;
+        }
+        if (k == 0) return fail(YOLO_E_UNSUPPORTED, "yolo_sumsq_f32_multi: tensor too large");
+        tab.first[k] = (int)chunks;
+        tab.count = k;
+        if (chunks > 0) {
+            hipLaunchKernelGGL(sumsq_multi_kernel, dim3((unsigned)chunks), dim3(256), 0, STRM(stream), tab, acc);
+            if (int rc = check_launch("yolo_sumsq_f32_multi")) return rc;
+        }
+        base += k;
+    }
+    return 0;
+}
+
+YOLO_API int yolo_adam_step_multi(const yolo_adam_tensor *t, int count, float lr, float beta1, float beta2, float eps, float weight_decay, long step,
+                                  const double *norm_sq, float max_norm, yolo_stream_t stream)
+{
+    if (!t || count < 0 || step < 1) return fail(YOLO_E_ARG, "yolo_adam_step_multi: bad argument");
+    const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+    const float step_size = (float)((double)lr / bc1);
+    const float inv_bc2_sqrt = (float)(1.0 / sqrt(bc2));
+    for (int base = 0; base < count;) {
+        AdamTable tab{};
+        long chunks = 0;
+        int k = 0;
+        for (; base + k < count && k < YOLO_MT_MAX; ++k) {
+            const yolo_adam_tensor &e = t[base + k];
+            if (!e.p || !e.g || !e.m || !e.v || e.n < 0) return fail(YOLO_E_ARG, "yolo_adam_step_multi: tensor %d: null pointer or negative size", base + k);
+            if (((uintptr_t)e.p | (uintptr_t)e.g | (uintptr_t)e.m | (uintptr_t)e.v) & 15) return fail(YOLO_E_UNSUPPORTED, "yolo_adam_step_multi: tensor %d is not 16-B aligned", base + k);
+            if ((uintptr_t)e.p_bf16 & 7) return fail(YOLO_E_UNSUPPORTED, "yolo_adam_step_multi: bf16 shadow %d is not 8-B aligned", base + k);
+            const long c = (e.n + MT_CHUNK - 1) / MT_CHUNK;
+            if (chunks + c > 0x7fffffffL) break;
+            tab.t[k] = e; tab.first[k] = (int)chunks;
+            chunks += c;
+        }
+        if (k == 0) return fail(YOLO_E_UNSUPPORTED, "yolo_adam_step_multi: tensor too large");
+        tab.first[k] = (int)chunks;
+        tab.count = k;
+        if (chunks > 0) {
+            hipLaunchKernelGGL(adam_multi_kernel, dim3((unsigned)chunks), dim3(256), 0, STRM(stream), tab, beta1, beta2, eps, weight_decay, step_size,
+                               inv_bc2_sqrt, norm_sq, max_norm);
+            if (int rc = check_launch("yolo_adam_step_multi")) return rc;
+        }
+        base += k;
+    }
+    return 0;
 }
 
 YOLO_API int yolo_clip_scale_f32(float *g, long n, const double *norm_sq, float max_norm, yolo_stream_t stream)

@@ -60,6 +60,24 @@ class PoolDesc(ctypes.Structure):
                 ("in_halo", ctypes.c_int32), ("out_halo", ctypes.c_int32)]
 
 
+class AdamTensor(ctypes.Structure):
+    """struct yolo_adam_tensor (include/yolo_hip.h)."""
+
+    _fields_ = [("p", c_void_p), ("g", c_void_p), ("m", c_void_p), ("v", c_void_p), ("p_bf16", c_void_p), ("n", ctypes.c_long)]
+
+
+class ConvPackItem(ctypes.Structure):
+    """struct yolo_conv_pack_item (include/yolo_hip.h)."""
+
+    _fields_ = [("w", c_void_p), ("wf", c_void_p), ("wd", c_void_p), ("Cout", c_int), ("Cin", c_int), ("KH", c_int), ("KW", c_int)]
+
+
+class ConvUnpackItem(ctypes.Structure):
+    """struct yolo_conv_unpack_item (include/yolo_hip.h)."""
+
+    _fields_ = [("dwp", c_void_p), ("dw", c_void_p), ("Cout", c_int), ("Cin", c_int), ("KH", c_int), ("KW", c_int)]
+
+
 EPI_NONE, EPI_BIAS, EPI_BIAS_LRELU, EPI_MUL_DLRELU, EPI_BIAS_ADD_LRELU = 0, 1, 2, 3, 4
 NMS_INFERENCE, NMS_METRICS = 0, 1
 
@@ -88,11 +106,17 @@ _SIGS = {
     "yolo_unpack_conv_wgrad": [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p],
     "yolo_im2col_rows": [c_void_p, c_long, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p],
     "yolo_transpose_f32_to_bf16": [c_void_p, c_int, c_int, c_void_p, c_int, c_void_p],
+    "yolo_transpose_bf16": [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p],
+    "yolo_fc_dgrad_to_nhwc": [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_float, c_void_p, c_void_p],
     "yolo_cast_f32_to_bf16": [c_void_p, c_long, c_void_p, c_void_p],
     "yolo_cast_bf16_to_f32": [c_void_p, c_long, c_void_p, c_void_p],
     "yolo_sumsq_f32": [c_void_p, c_long, c_void_p, c_void_p],
     "yolo_adam_step": [c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_float, c_float, c_float, c_float, c_float, c_long, c_void_p, c_float, c_void_p, c_void_p],
     "yolo_clip_scale_f32": [c_void_p, c_long, c_void_p, c_float, c_void_p],
+    "yolo_pack_conv_weights_multi": [ctypes.POINTER(ConvPackItem), c_int, c_void_p],
+    "yolo_unpack_conv_wgrads_multi": [ctypes.POINTER(ConvUnpackItem), c_int, c_void_p],
+    "yolo_sumsq_f32_multi": [c_void_p, c_void_p, c_int, c_void_p, c_void_p],
+    "yolo_adam_step_multi": [ctypes.POINTER(AdamTensor), c_int, c_float, c_float, c_float, c_float, c_float, c_long, c_void_p, c_float, c_void_p],
     "yolo_bias_lrelu_rows": [c_void_p, c_void_p, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p],
 }
 

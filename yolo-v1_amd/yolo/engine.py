@@ -24,7 +24,8 @@ import torch
 import torch.nn as nn
 
 from . import _hip
-from ._hip import (EPI_BIAS, EPI_BIAS_LRELU, EPI_MUL_DLRELU, EPI_NONE, IgemmDesc, PoolDesc, WgradDesc, check, lib, ptr, stream)
+from ._hip import (EPI_BIAS, EPI_BIAS_LRELU, EPI_MUL_DLRELU, EPI_NONE, ConvPackItem, ConvUnpackItem, IgemmDesc, PoolDesc, WgradDesc, check, lib, ptr,
+                   stream)
 
 
 def _round_up(a: int, b: int) -> int:
@@ -188,7 +189,8 @@ class Plan:
         for L in layers:
             if L.kind in ("conv", "fc"):
                 self.params += [L.weight, L.bias]
-        self._packed: dict[int, tuple] = {}
+        self._pf: dict[int, tuple] = {}
+        self._pd: dict[int, tuple] = {}
         self._ws: dict[tuple, list] = {}
         self.debug_keep = False      # tests: keep the last workspace (activations + gradients) for inspection
         self.last = None
@@ -220,14 +222,6 @@ class Plan:
                                  self.arena[bv[li][0]:bv[li][1]].view_as(self.layers[li].bias), wv[li][0], wv[li][2])
                             for li in order}
         return self.arena
-
-    def _grad_tensors(self, li: int, dev):
-        """(dw, db) destination for layer li: arena views or fresh tensors; db is zero-filled."""
-        L = self.layers[li]
-        if self.arena is not None:
-            dw, db, _, _ = self.arena_views[li]
-            return dw, db
-        return torch.empty_like(L.weight, dtype=torch.float32), torch.zeros_like(L.bias, dtype=torch.float32)
 
     def _layer_done(self, li: int):
         if self.arena is not None and self.on_grad_ready is not None:
@@ -285,37 +279,111 @@ class Plan:
         return Plan(layers, in_channels, input_is_image)
 
     # ------------------------------------------------------------------ weights
-    def _pack(self, li: int, need_dgrad: bool):
-        L = self.layers[li]
-        w = L.weight
-        key = (w._version, w.data_ptr(), need_dgrad)
-        hit = self._packed.get(li)
-        if hit is not None and hit[0][0] == key[0] and hit[0][1] == key[1] and (hit[0][2] or not need_dgrad):
-            return hit[1], hit[2]
-        dev = w.device
-        wd = None
-        wsrc = w.detach()
+    # bf16 operand copies of the fp32 masters, cached per layer and keyed on (tensor version, storage):
+    #   _pf[li] = (key, forward operand)        conv: [Cout][KH][KW][Cin]      Linear: [O][K] (the master's layout)
+    #   _pd[li] = (key, data-gradient operand)  conv: [Cin][KH][KW][Cout] flipped   Linear: [K][ld(O)] (only the
+    #             small Linear layers; the big one in front of nn.Flatten uses the forward copy, see backward)
+    @staticmethod
+    def _wkey(w):
+        return (w._version, w.data_ptr())
+
+    def _multi_ok(self, L: Layer) -> bool:
+        return L.kind == "conv" and not L.first and L.Cout % 64 == 0 and L.Cin % 64 == 0 and L.K * L.K <= 9
+
+    def _src(self, L: Layer):
+        wsrc = L.weight.detach()
         if wsrc.dtype != torch.float32 or not wsrc.is_contiguous():
             wsrc = wsrc.float().contiguous()
+        return wsrc
+
+    def _pack_all(self, need_dgrad: bool):
+        """Refresh every stale conv operand of the plan in ONE launch (yolo_pack_conv_weights_multi)."""
+        items, keep, done = [], [], []
+        for li, L in enumerate(self.layers):
+            if not self._multi_ok(L):
+                continue
+            key = self._wkey(L.weight)
+            f, d = self._pf.get(li), self._pd.get(li)
+            want_f = f is None or f[0] != key
+            want_d = need_dgrad and li > 0 and (d is None or d[0] != key)
+            if not (want_f or want_d):
+                continue
+            dev = L.weight.device
+            wsrc = self._src(L)
+            keep.append(wsrc)
+            wf = wd = None
+            if want_f:
+                wf = f[1] if f is not None else torch.empty((L.Cout, L.K, L.K, L.Cin), dtype=torch.bfloat16, device=dev)
+            if want_d:
+                wd = d[1] if d is not None else torch.empty((L.Cin, L.K, L.K, L.Cout), dtype=torch.bfloat16, device=dev)
+            items.append(ConvPackItem(wsrc.data_ptr(), wf.data_ptr() if wf is not None else None, wd.data_ptr() if wd is not None else None,
+                                      L.Cout, L.Cin, L.K, L.K))
+            done.append((li, key, wf, wd))
+        if items:
+            tab = (ConvPackItem * len(items))(*items)
+            check(lib().yolo_pack_conv_weights_multi(tab, len(items), stream()), "pack_conv_weights_multi")
+            for li, key, wf, wd in done:
+                if wf is not None:
+                    self._pf[li] = (key, wf)
+                if wd is not None:
+                    self._pd[li] = (key, wd)
+
+    def _pack(self, li: int, need_dgrad: bool):
+        """(forward operand, data-gradient operand | None) of layer li, refreshed if the master changed."""
+        L = self.layers[li]
+        key = self._wkey(L.weight)
+        f, d = self._pf.get(li), self._pd.get(li)
+        ok_f = f is not None and f[0] == key
+        ok_d = d is not None and d[0] == key
+        if ok_f and (ok_d or not need_dgrad):
+            return f[1], (d[1] if ok_d else None)
+        dev = L.weight.device
+        wsrc = self._src(L)
+        wf = f[1] if f is not None else None
+        wd = d[1] if d is not None else None
         if L.kind == "conv":
             if L.first:
-                wf = torch.empty((L.Cout, 7, 8, 4), dtype=torch.bfloat16, device=dev)
+                if wf is None:
+                    wf = torch.empty((L.Cout, 7, 8, 4), dtype=torch.bfloat16, device=dev)
                 check(lib().yolo_pack_conv_weight(ptr(wsrc), L.Cout, 3, 7, 7, 4, 8, ptr(wf), None, stream()), "pack_conv_weight")
-            else:
+                self._pf[li] = (key, wf)
+                return wf, None
+            if wf is None:
                 wf = torch.empty((L.Cout, L.K, L.K, L.Cin), dtype=torch.bfloat16, device=dev)
-                if need_dgrad:
-                    wd = torch.empty((L.Cin, L.K, L.K, L.Cout), dtype=torch.bfloat16, device=dev)
-                check(lib().yolo_pack_conv_weight(ptr(wsrc), L.Cout, L.Cin, L.K, L.K, L.Cin, L.K, ptr(wf), ptr(wd), stream()), "pack_conv_weight")
+            if need_dgrad and wd is None:
+                wd = torch.empty((L.Cin, L.K, L.K, L.Cout), dtype=torch.bfloat16, device=dev)
+            check(lib().yolo_pack_conv_weight(ptr(wsrc), L.Cout, L.Cin, L.K, L.K, L.Cin, L.K, None if ok_f else ptr(wf),
+                                              ptr(wd) if (need_dgrad and not ok_d) else None, stream()), "pack_conv_weight")
         else:
-            # forward operand in 128x64 panels: contiguous 16-KB stage reads of the weight stream
-            wf = torch.empty((_round_up(L.Cout, 128) * L.Cin,), dtype=torch.bfloat16, device=dev)
-            check(lib().yolo_pack_fc_weight_blocked(ptr(wsrc), L.Cout, L.Cin, ptr(wf), stream()), "pack_fc_blocked")
-            if need_dgrad:
+            if not ok_f:
+                if wf is None:
+                    wf = torch.empty((L.Cout, L.Cin), dtype=torch.bfloat16, device=dev)
+                check(lib().yolo_cast_f32_to_bf16(ptr(wsrc), wsrc.numel(), ptr(wf), stream()), "cast fc weight")
+            if need_dgrad and not ok_d:
                 ld = _round_up(L.Cout, 32)
-                wd = torch.zeros((L.Cin, ld), dtype=torch.bfloat16, device=dev)
+                if wd is None:
+                    wd = torch.zeros((L.Cin, ld), dtype=torch.bfloat16, device=dev)
                 check(lib().yolo_transpose_f32_to_bf16(ptr(wsrc), L.Cout, L.Cin, ptr(wd), ld, stream()), "transpose")
-        self._packed[li] = (key, wf, wd)
-        return wf, wd
+        self._pf[li] = (key, wf)
+        if need_dgrad:
+            self._pd[li] = (key, wd)
+            return wf, wd
+        return wf, (wd if ok_d else None)
+
+    def bf16_shadows(self):
+        """[(param, bf16 forward operand with the master's layout, callback)] for the Linear layers: an optimizer
+        that writes bf16(p) into the operand while it updates p calls ``callback(p)`` afterwards
+        (yolo.optim.Adam.attach_plan), which saves the 822 MB + 411 MB re-cast of the big Linear per step."""
+        out = []
+        for li, L in enumerate(self.layers):
+            if L.kind != "fc" or not L.weight.is_cuda:
+                continue
+            wf, _ = self._pack(li, False)
+
+            def fresh(p, li=li, wf=wf):
+                self._pf[li] = (self._wkey(p), wf)
+            out.append((L.weight, wf, fresh))
+        return out
 
     # ------------------------------------------------------------------ workspace
     def _workspace(self, N: int, x_shape, device, train: bool):
@@ -386,6 +454,7 @@ class Plan:
         if x.dtype != torch.float32 or not x.is_contiguous():
             x = x.float().contiguous()
         key, ws = self._workspace(N, x.shape, dev, train)
+        self._pack_all(train)
         a = ws["in"]
         if a.C == 4 and a.halo == 3:
             check(L_.yolo_nchw_f32_to_nhwc_bf16(ptr(x), N, x.shape[1], x.shape[2], x.shape[3], a.p, 4, 3, 3, st), "nchw->nhwc4")
@@ -434,7 +503,6 @@ class Plan:
                 d.out_img_stride, d.out_row_stride, d.out_px_stride, d.out_off = L.Cout, 0, L.Cout, 0
                 d.slope = self.SLOPE
                 d.out_fp32 = 1
-                d.w_blocked = 1
                 last = (li == len(self.layers) - 1)
                 nk = K // 64
                 splits = max(1, min(32, nk // 16)) if K >= 4096 else 1
@@ -505,6 +573,45 @@ class Plan:
             self.arena[self._arena_w_end:].zero_()      # bias gradients are accumulated with atomics
         grads: dict[int, tuple] = {}
         nl = len(self.layers)
+        # one zero-filled fp32 scratch for the whole pass: the packed conv weight gradients (targets of
+        # yolo_wgrad's atomics) and, without an arena, the bias gradients -- one fill instead of ~50
+        offs, tot = {}, 0
+        for i, L in enumerate(self.layers):
+            if L.kind == "conv":
+                offs[("w", i)] = tot
+                tot += _round_up(L.Cout * 7 * 8 * 4 if L.first else L.Cout * L.K * L.K * L.Cin, 64)
+        if self.arena is None:
+            for i, L in enumerate(self.layers):
+                if L.kind in ("conv", "fc"):
+                    offs[("b", i)] = tot
+                    tot += _round_up(L.Cout, 64)
+        scratch = torch.zeros(tot, dtype=torch.float32, device=dev)
+
+        def grad_tensors(i):
+            L = self.layers[i]
+            if self.arena is not None:
+                dw, db, _, _ = self.arena_views[i]
+                return dw, db
+            o = offs[("b", i)]
+            return torch.empty_like(L.weight, dtype=torch.float32), scratch[o: o + L.Cout]
+
+        # packed -> OIHW conversion of finished conv gradients is deferred and done for several layers per
+        # launch (yolo_unpack_conv_wgrads_multi); gradients become final (and are announced) at the flush
+        pending: list[tuple] = []
+
+        def flush():
+            items = [ConvUnpackItem(dwp.data_ptr(), dw.data_ptr(), L.Cout, L.Cin, L.K, L.K) for (i, L, dwp, dw) in pending if self._multi_ok(L)]
+            if items:
+                check(L_.yolo_unpack_conv_wgrads_multi((ConvUnpackItem * len(items))(*items), len(items), st), "unpack_conv_wgrads_multi")
+            for (i, L, dwp, dw) in pending:
+                if not self._multi_ok(L):
+                    if L.first:
+                        check(L_.yolo_unpack_conv_wgrad(ptr(dwp), L.Cout, 3, 7, 7, 4, 8, ptr(dw), 0, st), "unpack")
+                    else:
+                        check(L_.yolo_unpack_conv_wgrad(ptr(dwp), L.Cout, L.Cin, L.K, L.K, L.Cin, L.K, ptr(dw), 0, st), "unpack")
+                self._layer_done(i)
+            pending.clear()
+
         gout = gout.detach()
         if gout.dtype != torch.float32 or not gout.is_contiguous():
             gout = gout.float().contiguous()
@@ -544,14 +651,47 @@ class Plan:
                 check(L_.yolo_scale_rows_to_bf16(ptr(g_flat), ptr(mask), (1.0 / (1.0 - L.dropout)) if mask is not None else 1.0,
                                                  ptr(y_act) if (L.lrelu and not last) else None, self.SLOPE, N, L.Cout, ldg, ptr(gb), st), "scale_rows")
                 # weight / bias gradient, native [O][K] layout
-                dw, db = self._grad_tensors(li, dev)
+                dw, db = grad_tensors(li)
                 wd = WgradDesc(N, ldg, L.Cin, L.Cout, L.Cin, 1, 1, 0, 0, 1, 0)
                 with _timed(f"fc{li}.wgrad", "wgrad", 2.0 * N * L.Cout * L.Cin):
                     check(L_.yolo_wgrad(ctypes.byref(wd), ptr(xin), ptr(gb), ptr(dw), ptr(db), st), f"wgrad fc{li}")
                 grads[li] = (dw, db)
                 self._layer_done(li)
-                # data gradient -> fp32 (N, K)
+                # data gradient
                 need_prev = li > 0 or need_gx
+                behind_flatten = li >= 2 and self.layers[li - 1].kind == "flatten" and self.layers[li - 2].kind in ("conv", "pool")
+                if need_prev and behind_flatten:
+                    # the Linear behind nn.Flatten (205 M weights): reduce over the OUTPUT features with the
+                    # weight-gradient kernel -- both operands are strided along the reduction axis there, which
+                    # is exactly how W[o][k] and g^T[o][n] lie in memory -- and read the forward bf16 copy of W:
+                    #   dxT[k][n] = sum_o W[o][k] * gT[o][n]
+                    Lc = self.layers[li - 2]
+                    y = ws["acts"][li - 2]
+                    wf, _ = self._pack(li, False)
+                    ldn = _round_up(N, 8)
+                    gT = torch.zeros((L.Cout, ldn), dtype=torch.bfloat16, device=dev)
+                    check(L_.yolo_transpose_bf16(ptr(gb), N, L.Cout, ldg, ptr(gT), ldn, st), "transpose g")
+                    dxT = torch.zeros((L.Cin, N), dtype=torch.float32, device=dev)
+                    tiles = (L.Cin + 127) // 128
+                    split = max(1, min((L.Cout + 63) // 64, (1024 + tiles - 1) // tiles))
+                    wd = WgradDesc(L.Cout, L.Cin, ldn, L.Cin, N, 1, 1, 0, 0, split, 1)
+                    with _timed(f"fc{li}.dgrad", "wgrad", 2.0 * N * L.Cout * L.Cin):
+                        check(L_.yolo_wgrad(ctypes.byref(wd), ptr(gT), ptr(wf), ptr(dxT), None, st), f"dgrad fc{li}")
+                    if Lc.kind == "conv":
+                        assert Lc.stride == 1, "nn.Flatten is expected after a stride-1 conv or a pool"
+                        g = self._grad_buf(ws, li - 2, N, dev)
+                        yact = y.p if Lc.lrelu else None
+                    else:
+                        g = ws["misc"].get("graw_flat")
+                        if g is None:
+                            g = Act(N, y.H, y.W, y.C, 1, dev)
+                            ws["misc"]["graw_flat"] = g
+                        yact = None
+                    check(L_.yolo_fc_dgrad_to_nhwc(ptr(dxT), N, y.C, y.H, y.W, 1, yact, self.SLOPE, g.p, st), "fc_dgrad_to_nhwc")
+                    g_act = g
+                    g_flat = None
+                    li -= 2          # nn.Flatten is done as well
+                    continue
                 if need_prev:
                     _, wt = self._pack(li, True)
                     d = IgemmDesc()
@@ -560,34 +700,13 @@ class Plan:
                     d.stride, d.KH, d.KW, d.tap_len, d.Cout = 1, 1, 1, ldg, L.Cin
                     d.out_img_stride, d.out_row_stride, d.out_px_stride, d.out_off = L.Cin, 0, L.Cin, 0
                     d.epilogue, d.slope, d.out_fp32, d.split_k = EPI_NONE, self.SLOPE, 1, 1
-                    aux = None
-                    if li >= 2 and self.layers[li - 1].kind == "flatten" and self.layers[li - 2].kind == "conv" and self.layers[li - 2].lrelu:
-                        # LeakyReLU' of the conv in front of nn.Flatten, read from the flattened activation itself
-                        d.epilogue = EPI_MUL_DLRELU
-                        d.aux_img_stride, d.aux_row_stride, d.aux_px_stride, d.aux_off = L.Cin, 0, L.Cin, 0
-                        aux = ptr(xin)
                     gprev = torch.empty((N, L.Cin), dtype=torch.float32, device=dev)
                     with _timed(f"fc{li}.dgrad", "igemm", 2.0 * N * L.Cout * L.Cin):
-                        check(L_.yolo_igemm(ctypes.byref(d), ptr(gb), ptr(wt), None, aux, ptr(gprev), st), f"dgrad fc{li}")
+                        check(L_.yolo_igemm(ctypes.byref(d), ptr(gb), ptr(wt), None, None, ptr(gprev), st), f"dgrad fc{li}")
                     g_flat = gprev
                 li -= 1
             elif L.kind == "flatten":
-                # g_flat is the NCHW-flatten gradient of the conv stack's output (pre LeakyReLU')
-                y = input_of(li)  # Act of the last conv
-                lc = li - 1
-                Lc = self.layers[lc]
-                if Lc.kind == "conv" and Lc.stride == 1:
-                    # LeakyReLU' was already applied by the fc data-gradient epilogue
-                    g = self._grad_buf(ws, lc, N, dev)
-                else:
-                    g = ws["misc"].get("graw_flat")
-                    if g is None:
-                        g = Act(N, y.H, y.W, y.C, 1, dev)
-                        ws["misc"]["graw_flat"] = g
-                    assert Lc.kind == "pool", "nn.Flatten is expected after a stride-1 conv or a pool"
-                check(L_.yolo_nchw_f32_to_nhwc_bf16(ptr(g_flat), N, y.C, y.H, y.W, g.p, y.C, 1, 1, st), "gflat->nhwc")
-                g_act = g
-                li -= 1
+                raise AssertionError("nn.Flatten is handled together with the Linear layer behind it")
             elif L.kind == "pool":
                 # g_act = gradient wrt the pooled output; produce gradient wrt the conv in front
                 lc = li - 1
@@ -604,29 +723,30 @@ class Plan:
                 g = g_act  # dZ of this layer, flat-geometry buffer
                 xin = input_of(li)
                 # ---- weight + bias gradient
-                dw, db = self._grad_tensors(li, dev)
+                dw, db = grad_tensors(li)
+                o = offs[("w", li)]
                 if L.first:
                     xcol = ws["misc"].get("xcol")
                     if xcol is None:
                         xcol = Act(N, L.Hout, L.Wout, 7 * 32, 1, dev)
                         ws["misc"]["xcol"] = xcol
                     check(L_.yolo_im2col_rows(xin.p, xin.img_stride, xin.row_stride, xin.px_stride, 2, 7, 32, N, L.Hout, L.Wout, 1, xcol.p, st), "im2col_rows")
-                    dwp = torch.zeros((L.Cout, 7, 8, 4), dtype=torch.float32, device=dev)
+                    dwp = scratch[o: o + L.Cout * 7 * 8 * 4]
                     split = max(1, min(1024, g.slots // 4096))
                     wd = WgradDesc(g.slots, g.px_stride, xcol.px_stride, L.Cout, 7 * 32, 1, 1, 0, xcol.row_stride, split, 0)
                     with _timed(f"conv{li}.wgrad", "wgrad", 2.0 * N * L.Hout * L.Wout * L.Cout * 147):
                         check(L_.yolo_wgrad(ctypes.byref(wd), xcol.p, g.p, ptr(dwp), ptr(db), st), "wgrad conv0")
-                    check(L_.yolo_unpack_conv_wgrad(ptr(dwp), L.Cout, 3, 7, 7, 4, 8, ptr(dw), 0, st), "unpack")
                 else:
-                    dwp = torch.zeros((L.Cout, L.K, L.K, L.Cin), dtype=torch.float32, device=dev)
+                    dwp = scratch[o: o + L.Cout * L.K * L.K * L.Cin]
                     tiles = ((L.Cout + 127) // 128) * ((L.Cin + 127) // 128) * L.K * L.K
                     split = max(1, min(g.slots // 256, (1024 + tiles - 1) // tiles))
                     wd = WgradDesc(g.slots, g.px_stride, xin.px_stride, L.Cout, L.Cin, L.K, L.K, L.pad, xin.row_stride, split, 0)
                     with _timed(f"conv{li}.wgrad", "wgrad", 2.0 * N * L.Hout * L.Wout * L.Cout * L.Cin * L.K * L.K):
                         check(L_.yolo_wgrad(ctypes.byref(wd), xin.p, g.p, ptr(dwp), ptr(db), st), f"wgrad conv{li}")
-                    check(L_.yolo_unpack_conv_wgrad(ptr(dwp), L.Cout, L.Cin, L.K, L.K, L.Cin, L.K, ptr(dw), 0, st), "unpack")
                 grads[li] = (dw, db)
-                self._layer_done(li)
+                pending.append((li, L, dwp, dw))
+                if li == 0 or sum(t[2].numel() for t in pending) >= (16 << 20):
+                    flush()
                 # ---- data gradient
                 if li == 0:
                     gx = None

@@ -12,18 +12,24 @@ from __future__ import annotations
 
 import torch
 
+import ctypes
+
 from . import _hip
-from ._hip import check, lib, ptr, stream
+from ._hip import AdamTensor, check, lib, ptr, stream
+
+
+def _f32c(g: torch.Tensor) -> torch.Tensor:
+    return g if (g.dtype == torch.float32 and g.is_contiguous()) else g.float().contiguous()
 
 
 def grad_norm_sq(params) -> torch.Tensor:
-    """device double holding sum over all gradients of g^2 (enqueued, not synchronised)."""
-    grads = [p.grad for p in params if p.grad is not None]
+    """device double holding sum over all gradients of g^2 (enqueued, not synchronised): one launch
+    for the whole list (yolo_sumsq_f32_multi)."""
+    grads = [_f32c(p.grad) for p in params if p.grad is not None]
     acc = torch.zeros((), dtype=torch.float64, device=grads[0].device)
-    st = stream()
-    for g in grads:
-        g = g if (g.dtype == torch.float32 and g.is_contiguous()) else g.float().contiguous()
-        check(lib().yolo_sumsq_f32(ptr(g), g.numel(), ptr(acc), st), "yolo_sumsq_f32")
+    gp = (ctypes.c_void_p * len(grads))(*[g.data_ptr() for g in grads])
+    gn = (ctypes.c_long * len(grads))(*[g.numel() for g in grads])
+    check(lib().yolo_sumsq_f32_multi(gp, gn, len(grads), ptr(acc), stream()), "yolo_sumsq_f32_multi")
     return acc
 
 
@@ -47,7 +53,7 @@ class Adam(torch.optim.Optimizer):
             raise ValueError("invalid Adam hyper-parameter")
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
         self.max_grad_norm = max_grad_norm
-        self.bf16_shadow: dict[int, torch.Tensor] = {}   # id(param) -> bf16 tensor to refresh in the same pass
+        self.bf16_shadow: dict[int, tuple] = {}   # id(param) -> (bf16 tensor refreshed in the same pass, callback(param) | None)
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -63,23 +69,41 @@ class Adam(torch.optim.Optimizer):
         st = stream()
         for group in self.param_groups:
             b1, b2 = group["betas"]
+            # one launch per (group, step count): normally ONE launch for the whole model
+            by_step: dict[int, list] = {}
+            keep = []                      # temporaries the launch reads must outlive the enqueue
             for p in group["params"]:
                 if p.grad is None:
                     continue
-                g = p.grad
-                if g.dtype != torch.float32 or not g.is_contiguous():
-                    g = g.float().contiguous()
+                if p.dtype != torch.float32 or not p.is_contiguous():
+                    raise RuntimeError("yolo.optim.Adam needs contiguous fp32 parameters")
+                g = _f32c(p.grad)
+                keep.append(g)
                 state = self.state[p]
                 if len(state) == 0:
                     state["step"] = torch.tensor(0.0, dtype=torch.float32)
                     state["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                     state["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                 state["step"] += 1
-                shadow = self.bf16_shadow.get(id(p))
-                check(lib().yolo_adam_step(ptr(p), ptr(g), ptr(state["exp_avg"]), ptr(state["exp_avg_sq"]), p.numel(),
-                                           float(group["lr"]), float(b1), float(b2), float(group["eps"]), float(group["weight_decay"]),
-                                           int(state["step"].item()), ptr(norm), float(self.max_grad_norm or 0.0), ptr(shadow), st), "yolo_adam_step")
-                # the kernel updated p through a raw pointer: bump the autograd version so that the
-                # engine's packed bf16 copies notice (no memory traffic)
-                torch.autograd.graph.increment_version(p)
+                hook = self.bf16_shadow.get(id(p))
+                shadow = hook[0] if hook is not None else None
+                by_step.setdefault(int(state["step"].item()), []).append(
+                    (p, AdamTensor(p.data_ptr(), g.data_ptr(), state["exp_avg"].data_ptr(), state["exp_avg_sq"].data_ptr(),
+                                   shadow.data_ptr() if shadow is not None else None, p.numel()), hook))
+            for step, items in by_step.items():
+                tab = (AdamTensor * len(items))(*[it[1] for it in items])
+                check(lib().yolo_adam_step_multi(tab, len(items), float(group["lr"]), float(b1), float(b2), float(group["eps"]),
+                                                 float(group["weight_decay"]), step, ptr(norm), float(self.max_grad_norm or 0.0), st), "yolo_adam_step_multi")
+                for p, _, hook in items:
+                    # the kernel updated p through a raw pointer: bump the autograd version so that the
+                    # engine's packed bf16 copies notice (no memory traffic) ...
+                    torch.autograd.graph.increment_version(p)
+                    if hook is not None and hook[1] is not None:
+                        hook[1](p)         # ... and tell the owner of a shadow that it is already current
         return loss
+
+    def attach_plan(self, plan) -> None:
+        """Let this optimizer refresh the engine's bf16 forward operands of Linear layers in the same
+        pass that updates their fp32 masters (``plan``: ``model.hip_plan()``)."""
+        for p, shadow, fresh in plan.bf16_shadows():
+            self.bf16_shadow[id(p)] = (shadow, fresh)
