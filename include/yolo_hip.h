@@ -216,6 +216,15 @@ int yolo_pack_fc_weight_blocked(const float *w, int O, long K, void *w_panels_bf
 /* packed fp32 gradient [Cout][KH][KWp][Cinp] -> OIHW fp32 (accumulate=0: overwrite, 1: add). */
 int yolo_unpack_conv_wgrad(const float *dw_packed, int Cout, int Cin, int KH, int KW, int Cinp, int KWp,
                            float *dw_oihw, int accumulate, yolo_stream_t stream);
+/* Weight + bias gradient of the 7x7 / stride-2 / pad-3 stem conv (models.py:49; 3 input channels stored
+ * NHWC4 with halo 3, Cout = 64) WITHOUT the unfolded copy: the unfolding happens in the LDS read addresses of
+ * the MFMA operands.  dy: NHWC bf16 with 64 channels, dy_off = element offset of output pixel (0,0).
+ * Ho % 8 == 0 and Wo % 16 == 0 required (otherwise: yolo_im2col_rows + yolo_wgrad).  Writes (does not
+ * accumulate) dw in OIHW fp32 [64][3][7][7] and db[64] (NULL: skipped); deterministic: per-workgroup
+ * partials in `scratch` (>= 14400 floats; 768 * 14400 for full speed) are summed in a fixed order. */
+int yolo_wgrad_stem7(const void *x_nhwc4_bf16, const void *dy_bf16, int N, int Ho, int Wo, long x_img_stride,
+                     int x_row_stride, long dy_img_stride, int dy_row_stride, int dy_off, float *dw_oihw,
+                     float *db, float *scratch, long scratch_elems, yolo_stream_t stream);
 /* Whole-model forms of the two calls above: every conv layer of the model in ONE launch (LDS-tiled,
  * all HBM accesses in runs of >= 128 B).  Layers need Cout % 64 == 0 (unpack: % 4), Cin % 64 == 0,
  * KH*KW <= 9 and no padding (Cinp = Cin, KWp = KW); either output of a pack item may be NULL. */

@@ -237,6 +237,43 @@ def test_multi_layer_pack_and_unpack_are_exact():
     assert lib().yolo_pack_conv_weights_multi((ConvPackItem * 1)(bad), 1, stream()) != 0
 
 
+def test_stem_wgrad_direct_kernel():
+    """yolo_wgrad_stem7 (7x7/s2 stem, unfolding in the LDS read addresses) vs fp32 torch on bf16-rounded operands:
+    several tiles per workgroup, N > 1, and bit-reproducible (fixed-order partial sums)."""
+    from yolo._hip import lib, check, ptr, stream
+    from yolo.engine import Act
+    torch.manual_seed(9)
+    N, H, W = 3, 64, 96                      # output 32 x 48 -> 4 x 3 tiles per image
+    x = torch.randn(N, 3, H, W, device="cuda")
+    dy = torch.randn(N, 64, H // 2, W // 2, device="cuda") * 0.25
+    xa = Act(N, H, W, 4, 3, x.device)
+    check(lib().yolo_nchw_f32_to_nhwc_bf16(ptr(x), N, 3, H, W, xa.p, 4, 3, 3, stream()))
+    ga = Act(N, H // 2, W // 2, 64, 1, x.device)
+    check(lib().yolo_nchw_f32_to_nhwc_bf16(ptr(dy), N, 64, H // 2, W // 2, ga.p, 64, 1, 1, stream()))
+    outs = []
+    for G in (768, 5):                       # 5 workgroups: every workgroup walks over several tiles
+        part = torch.full((G * 14400,), float("nan"), device="cuda")
+        dw = torch.full((64, 3, 7, 7), float("nan"), device="cuda")
+        db = torch.full((64,), float("nan"), device="cuda")
+        check(lib().yolo_wgrad_stem7(xa.p, ga.p, N, H // 2, W // 2, xa.img_stride, xa.row_stride, ga.img_stride, ga.row_stride, ga.interior_off(),
+                                     ptr(dw), ptr(db), ptr(part), part.numel(), stream()))
+        outs.append((dw, db))
+    xr = _bf(x).double().cpu().requires_grad_(True)
+    w = torch.zeros(64, 3, 7, 7, dtype=torch.float64, requires_grad=True)
+    b = torch.zeros(64, dtype=torch.float64, requires_grad=True)
+    F.conv2d(xr, w, b, stride=2, padding=3).backward(_bf(dy).double().cpu())
+    for dw, db in outs:
+        torch.testing.assert_close(dw.cpu().double(), w.grad, rtol=1e-4, atol=2e-3)
+        torch.testing.assert_close(db.cpu().double(), b.grad, rtol=1e-4, atol=2e-3)
+    dw2 = torch.empty_like(outs[0][0]); db2 = torch.empty_like(outs[0][1])
+    part = torch.empty((768 * 14400,), device="cuda")
+    check(lib().yolo_wgrad_stem7(xa.p, ga.p, N, H // 2, W // 2, xa.img_stride, xa.row_stride, ga.img_stride, ga.row_stride, ga.interior_off(),
+                                 ptr(dw2), ptr(db2), ptr(part), part.numel(), stream()))
+    assert torch.equal(dw2, outs[0][0]) and torch.equal(db2, outs[0][1])
+    assert lib().yolo_wgrad_stem7(xa.p, ga.p, N, 30, 48, xa.img_stride, xa.row_stride, ga.img_stride, ga.row_stride, ga.interior_off(),
+                                  ptr(dw2), ptr(db2), ptr(part), part.numel(), stream()) != 0
+
+
 def test_fc_dgrad_behind_flatten_matches_cpu():
     """Linear behind nn.Flatten: the data gradient goes through yolo_wgrad (transposed product) + yolo_fc_dgrad_to_nhwc."""
     torch.manual_seed(5)

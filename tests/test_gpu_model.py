@@ -234,11 +234,12 @@ def test_adam_refreshes_linear_bf16_operands():
         for p, q in zip(mods.parameters(), ref.parameters()):
             torch.testing.assert_close(p, q, rtol=2e-5, atol=2e-6)
     # the refreshed operands are what the next forward computes with
+    y1 = engine.run_plan(plan, x, False).detach()       # grad mode: the plain operands the optimizer maintains
+    plan._pf.clear(); plan._pd.clear()
+    y2 = engine.run_plan(plan, x, False).detach()
     with torch.no_grad():
-        y1 = engine.run_plan(plan, x, False)
-        plan._pf.clear(); plan._pd.clear()
-        y2 = engine.run_plan(plan, x, False)
-    assert torch.equal(y1, y2)
+        y3 = engine.run_plan(plan, x, False)            # inference: 128x64 panels packed from the fp32 master
+    assert torch.equal(y1, y2) and torch.equal(y1, y3)
 
 
 def test_detection_head_on_the_engine():

@@ -87,6 +87,7 @@ __global__ void __launch_bounds__(256) adam_kernel(float *__restrict__ p, const 
 }
 
 constexpr int MT_CHUNK = 8192;  // elements per workgroup: 256 lanes x float4 x 8
+constexpr int SQ_CHUNK = 65536; // the norm kernel ends in ONE fp64 atomic per workgroup on one address: keep them few
 
 struct SumsqTable {
     const float *g[YOLO_MT_MAX];
@@ -112,8 +113,8 @@ __global__ void __launch_bounds__(256) sumsq_multi_kernel(const SumsqTable tab, 
     const int ti = find_tensor(tab.first, tab.count, blockIdx.x);
     const float *__restrict__ g = tab.g[ti];
     const long n = tab.n[ti];
-    const long beg = (long)(blockIdx.x - tab.first[ti]) * MT_CHUNK;
-    const long end = min(n, beg + MT_CHUNK);
+    const long beg = (long)(blockIdx.x - tab.first[ti]) * SQ_CHUNK;
+    const long end = min(n, beg + SQ_CHUNK);
     double s = 0.0;
     for (long i = beg + threadIdx.x * 4; i < end; i += 1024) {
         if (i + 4 <= end) {
@@ -233,7 +234,7 @@ YOLO_API int yolo_sumsq_f32_multi(const float *const *g, const long *n, int coun
             const long nn = n[base + k];
             if (!gp || nn < 0) return fail(YOLO_E_ARG, "yolo_sumsq_f32_multi: tensor %d: null pointer or negative size", base + k);
             if ((uintptr_t)gp & 15) return fail(YOLO_E_UNSUPPORTED, "yolo_sumsq_f32_multi: tensor %d is not 16-B aligned", base + k);
-            const long c = (nn + MT_CHUNK - 1) / MT_CHUNK;
+            const long c = (nn + SQ_CHUNK - 1) / SQ_CHUNK;
             if (chunks + c > 0x7fffffffL) break;
             tab.g[k] = gp; tab.n[k] = nn; tab.first[k] = (int)chunks;
             chunks += c;

@@ -17,6 +17,8 @@
 // Split over pixel ranges (blockIdx.y) with fp32 atomics into the packed gradient.
 // Replaces the weight-gradient half of aten convolution_backward / addmm backward for
 // src/yolo/models.py:47-84,239-245,313-332.
+#include <algorithm>
+
 #include "common.h"
 
 namespace yolo {
@@ -206,6 +208,164 @@ __global__ void __launch_bounds__(256, 2) wgrad_kernel(const WgradParams p)
         }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Weight + bias gradient of the 7x7 / stride-2 / pad-3 stem (3 input channels stored NHWC4, 64 outputs;
+// src/yolo/models.py:49).  No channel-contiguous reduction axis exists for Cin = 3, so the generic kernel
+// needed a 1.4 GB row-unfolded copy of the input (yolo_im2col_rows); here the unfolding happens in the
+// LDS READ ADDRESSES instead:
+//   D[co][(ky, kx, c)] += sum_px dy[px][co] * x[2*oy + ky][2*ox + kx][c]
+// workgroup = 8 x 16 output pixels of one image.  dy tile [128 px][64 co] and the raw input patch
+// [21 rows][40 px][4 ch] are staged by LDS-DMA; both MFMA operands come from ds_read_b64_tr_b16, whose
+// per-lane addresses make "row px, 16 consecutive (kx, c) columns" a plain 32-byte run of the patch.
+// 4 waves = the 4 blocks of 16 output channels; 14 column blocks (7 ky x 2 halves of the kx-padded-to-8
+// row) x 4 pixel blocks of 32 -> 56 v_mfma_f32_16x16x32_bf16 per wave and tile.  A workgroup walks over
+// many tiles (double-buffered) and leaves ONE partial [64][7][8][4] (+64 bias sums) in a scratch buffer;
+// stem_wgrad_reduce_kernel sums the partials in a fixed order (deterministic, no atomics) straight into
+// the OIHW gradient.  HBM-bound: dy (411 MB at batch 64) is read exactly once.
+constexpr int ST_TH = 8, ST_TW = 16;           // tile of output pixels
+constexpr int ST_DY_BYTES = ST_TH * ST_TW * 64 * 2;   // 16 KB
+constexpr int ST_PW = 40, ST_PH = 21;          // patch pitch (pixels) and rows: 2*8+5, 2*16+5 (+kx pad) <= 40
+constexpr int ST_X_BYTES = 7 * 1024;           // 7 DMA wave-instructions >= 21*40*8 = 6720 B
+constexpr int ST_STAGE = ST_DY_BYTES + ST_X_BYTES;
+constexpr int ST_COLS = 7 * 8 * 4;             // 224 packed columns per output channel
+constexpr int ST_PART = 64 * ST_COLS + 64;     // floats per workgroup partial (weights + bias)
+
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+struct StemWgradParams {
+    const bf16_t *x;       // NHWC4, halo 3
+    const bf16_t *dy;      // NHWC 64 channels, any halo (dy_off = offset of pixel (0,0))
+    float *part;
+    int N, tiles_x, tiles_y, ntiles;
+    long x_img_stride, dy_img_stride;
+    int x_row_stride, dy_row_stride, dy_off;
+};
+
+__global__ void __launch_bounds__(256, 3) stem_wgrad_kernel(const StemWgradParams p)
+{
+    __shared__ __attribute__((aligned(16))) char bufA[ST_STAGE];
+    __shared__ __attribute__((aligned(16))) char bufB[ST_STAGE];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    // ---- DMA sources.  dy slot (k, c') holds 16-B chunk c = c' ^ s(k), s(k) = 2*bit1(k) + 4*bit3(k): the 32 lanes
+    // of a transposing read (4 rows x 2 row-groups x 4 column quads) then cover all 64 banks once.
+    int dy_off[4], x_off[2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int slot = (i * 4 + wave) * 64 + lane;
+        const int k = slot >> 3, cs = slot & 7;
+        const int c = cs ^ ((((k >> 1) & 1) << 1) | (((k >> 3) & 1) << 2));
+        dy_off[i] = (k >> 4) * p.dy_row_stride + (k & 15) * 64 + c * 8;
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        int slot = (i * 4 + wave) * 64 + lane;          // 16-B slots of the patch: 20 per row
+        if (slot >= ST_PH * (ST_PW / 2)) slot = ST_PH * (ST_PW / 2) - 1;
+        x_off[i] = (slot / (ST_PW / 2)) * p.x_row_stride + (slot % (ST_PW / 2)) * 8;
+    }
+    auto stage = [&](char *sb, int tile) {
+        const int tx = tile % p.tiles_x, r = tile / p.tiles_x;
+        const int ty = r % p.tiles_y, n = r / p.tiles_y;
+        const bf16_t *dyb = p.dy + (long)n * p.dy_img_stride + (long)(ty * ST_TH) * p.dy_row_stride + tx * ST_TW * 64 + p.dy_off;
+        const bf16_t *xb = p.x + (long)n * p.x_img_stride + (long)(ty * ST_TH * 2) * p.x_row_stride + tx * ST_TW * 2 * 4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) GLDS16(dyb + dy_off[i], sb + (i * 4 + wave) * 1024);
+        GLDS16(xb + x_off[0], sb + ST_DY_BYTES + wave * 1024);
+        if (wave < 3) GLDS16(xb + x_off[1], sb + ST_DY_BYTES + (4 + wave) * 1024);
+    };
+
+    // ---- fragment addresses: group g = lane>>4 (pixel sub-block of 8), q = (lane>>2)&3 (row), pp = lane&3 (column quad)
+    const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
+    int a_lo[4], a_hi[4], b_lo[4];
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {
+        const int k0 = kb * 32 + g * 8 + q, k1 = k0 + 4;
+        const int ch = wave * 2 + (pp >> 1);
+        a_lo[kb] = k0 * 128 + ((ch ^ ((((k0 >> 1) & 1) << 1) | (((k0 >> 3) & 1) << 2))) << 4) + (pp & 1) * 8;
+        a_hi[kb] = k1 * 128 + ((ch ^ ((((k1 >> 1) & 1) << 1) | (((k1 >> 3) & 1) << 2))) << 4) + (pp & 1) * 8;
+        b_lo[kb] = ST_DY_BYTES + ((2 * (k0 >> 4)) * ST_PW + 2 * (k0 & 15) + pp) * 8;   // pixel k0+4 lies 4 columns = 64 B further
+    }
+
+    f32x4 acc[14];
+#pragma unroll
+    for (int i = 0; i < 14; ++i) acc[i] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    float bsum = 0.0f;
+
+    typedef __attribute__((address_space(3))) s16x4 *lds_s16x4;
+    auto compute = [&](const char *sb) {
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) {
+            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(sb + a_lo[kb]));
+            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(sb + a_hi[kb]));
+            const bf16x8 af = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+#pragma unroll
+            for (int e = 0; e < 4; ++e) bsum += __uint_as_float(((unsigned)(unsigned short)lo[e]) << 16) + __uint_as_float(((unsigned)(unsigned short)hi[e]) << 16);
+#pragma unroll
+            for (int ky = 0; ky < 7; ++ky)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const char *bp = sb + b_lo[kb] + (ky * ST_PW + 4 * h) * 8;
+                    const s16x4 blo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(bp));
+                    const s16x4 bhi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(bp + 64));
+                    const bf16x8 bf = __builtin_bit_cast(bf16x8, __builtin_shufflevector(blo, bhi, 0, 1, 2, 3, 4, 5, 6, 7));
+                    acc[ky * 2 + h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bf, acc[ky * 2 + h], 0, 0, 0);
+                }
+        }
+    };
+
+    const int G = gridDim.x;
+    int tile = blockIdx.x;
+    if (tile < p.ntiles) stage(bufA, tile);
+    while (tile < p.ntiles) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tile + G < p.ntiles) stage(bufB, tile + G);
+        compute(bufA);
+        tile += G;
+        if (tile >= p.ntiles) break;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tile + G < p.ntiles) stage(bufA, tile + G);
+        compute(bufB);
+        tile += G;
+    }
+
+    // ---- partial: D row (co) = 4*(lane>>4) + reg, column = lane & 15 of block (ky, h)
+    float *out = p.part + (long)blockIdx.x * ST_PART;
+#pragma unroll
+    for (int nb = 0; nb < 14; ++nb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) out[(wave * 16 + 4 * g + r) * ST_COLS + nb * 16 + (lane & 15)] = acc[nb][r];
+    bsum += __shfl_xor(bsum, 16, 64);
+    bsum += __shfl_xor(bsum, 32, 64);
+    if (lane < 16) out[64 * ST_COLS + wave * 16 + lane] = bsum;
+}
+
+// dw[co][c][ky][kx] = sum_g part[g][co][ky][kx][c]  (c < 3, kx < 7), db[co] = sum_g part[g][64*224 + co];
+// workgroup = 16 outputs x 16 slices of the partial list
+__global__ void __launch_bounds__(256) stem_wgrad_reduce_kernel(const float *__restrict__ part, int G, float *__restrict__ dw, float *__restrict__ db)
+{
+    __shared__ float red[16][17];
+    const int j = blockIdx.x * 16 + (threadIdx.x & 15), sl = threadIdx.x >> 4;
+    float s = 0.0f;
+    if (j < ST_PART)
+        for (int gi = sl; gi < G; gi += 16) s += part[(long)gi * ST_PART + j];
+    red[sl][threadIdx.x & 15] = s;
+    __syncthreads();
+    if (sl == 0 && j < ST_PART) {
+        float t = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += red[k][threadIdx.x];
+        if (j >= 64 * ST_COLS) {
+            if (db) db[j - 64 * ST_COLS] = t;
+        } else {
+            const int c = j & 3, kx = (j >> 2) & 7, ky = (j >> 5) % 7, co = j / ST_COLS;
+            if (c < 3 && kx < 7) dw[((co * 3 + c) * 7 + ky) * 7 + kx] = t;
+        }
+    }
+}
+
 // db[c] += sum_p dy[p][c]  (bias gradient).  HBM-bound column sum: a workgroup covers w <= 256
 // 8-channel chunks (one 16-B load per thread) x R = 256/w pixel rows per pass, so every wave reads
 // whole contiguous pixel rows whatever the channel count; LDS reduction over R, one fp32 atomic per
@@ -255,6 +415,30 @@ __global__ void __launch_bounds__(256) colsum_kernel(const bf16_t *__restrict__ 
 }  // namespace yolo
 
 using namespace yolo;
+
+YOLO_API int yolo_wgrad_stem7(const void *x_nhwc4, const void *dy, int N, int Ho, int Wo, long x_img_stride, int x_row_stride, long dy_img_stride,
+                              int dy_row_stride, int dy_off, float *dw_oihw, float *db, float *scratch, long scratch_elems, yolo_stream_t stream)
+{
+    if (!x_nhwc4 || !dy || !dw_oihw || !scratch || N <= 0 || Ho <= 0 || Wo <= 0) return fail(YOLO_E_ARG, "yolo_wgrad_stem7: bad argument");
+    if ((Ho % ST_TH) || (Wo % ST_TW)) return fail(YOLO_E_UNSUPPORTED, "yolo_wgrad_stem7: output %dx%d is not a multiple of %dx%d (use yolo_im2col_rows + yolo_wgrad)", Ho, Wo, ST_TH, ST_TW);
+    if ((x_row_stride & 7) || (x_img_stride & 7) || (dy_row_stride & 7) || (dy_img_stride & 7) || (dy_off & 7) || ((uintptr_t)x_nhwc4 & 15) || ((uintptr_t)dy & 15))
+        return fail(YOLO_E_UNSUPPORTED, "yolo_wgrad_stem7: strides must be multiples of 8 elements and pointers 16-B aligned");
+    StemWgradParams p{};
+    p.x = (const bf16_t *)x_nhwc4; p.dy = (const bf16_t *)dy; p.part = scratch;
+    p.N = N; p.tiles_x = Wo / ST_TW; p.tiles_y = Ho / ST_TH;
+    const long nt = (long)N * p.tiles_x * p.tiles_y;
+    if (nt > 0x7fffffffL) return fail(YOLO_E_UNSUPPORTED, "yolo_wgrad_stem7: too many tiles");
+    p.ntiles = (int)nt;
+    p.x_img_stride = x_img_stride; p.dy_img_stride = dy_img_stride;
+    p.x_row_stride = x_row_stride; p.dy_row_stride = dy_row_stride; p.dy_off = dy_off;
+    long G = std::min<long>(nt, 768);
+    G = std::min<long>(G, scratch_elems / ST_PART);
+    if (G < 1) return fail(YOLO_E_ARG, "yolo_wgrad_stem7: scratch must hold at least %d floats", ST_PART);
+    hipLaunchKernelGGL(stem_wgrad_kernel, dim3((unsigned)G), dim3(256), 0, STRM(stream), p);
+    if (int rc = check_launch("yolo_wgrad_stem7")) return rc;
+    hipLaunchKernelGGL(stem_wgrad_reduce_kernel, dim3((ST_PART + 15) / 16), dim3(256), 0, STRM(stream), (const float *)scratch, (int)G, dw_oihw, db);
+    return check_launch("yolo_wgrad_stem7(reduce)");
+}
 
 YOLO_API int yolo_wgrad(const yolo_wgrad_desc *d, const void *x, const void *dy, float *dw, float *db, yolo_stream_t stream)
 {
