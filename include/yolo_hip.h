@@ -169,8 +169,12 @@ typedef struct yolo_wgrad_desc {
     int32_t Cout, Cin;
     int32_t KH, KW, pad;
     int64_t x_row_stride;            /* elements between input rows (multiple of 8)               */
-    int32_t split;                   /* pixel-range split (>= 1)                                  */
+    int32_t split;                   /* pixel-range split (uniform, 2-D grid).  0: the library's two-segment
+                                        schedule -- whole rounds of the chip's workgroup slots plus a finer-split
+                                        tail round; dw is then ALWAYS accumulated (caller zero-fills) */
     int32_t accumulate;              /* 1: add into dw even when split == 1                       */
+    int32_t variant;                 /* 0: choose; 1: 128x128 tile, 4 waves, 2 stages; 2: 256x128 tile,
+                                        8 waves, 3 stages (tests / tuning)                        */
 } yolo_wgrad_desc;
 
 int yolo_wgrad(const yolo_wgrad_desc *d, const void *x_bf16, const void *dy_bf16,

@@ -9,6 +9,10 @@ from yolo._hip import lib, check, ptr, stream, WgradDesc
 from yolo.engine import Act
 
 N = 64
+VARIANT = int(os.environ.get("VARIANT", "0"))
+MAP = int(os.environ.get("MAP", "0"))
+SPLITS = [int(v) for v in os.environ.get("SPLITS", "").split(",") if v]
+ONLY = [int(v) for v in os.environ.get("LAYERS", "").split(",") if v]
 dev = torch.device("cuda")
 h = 448
 rows = []
@@ -19,7 +23,7 @@ for item in synth.YOLOV1_BACKBONE_CFG:
     idx, (co, ci, k, s, p) = item
     hin = h
     h = (h + 2 * p - k) // s + 1
-    if idx == 0:
+    if idx == 0 or (ONLY and idx not in ONLY):
         continue
     geo = hin if s == 2 else h
     x = Act(N, geo, geo, ci, 1, dev)
@@ -28,8 +32,8 @@ for item in synth.YOLOV1_BACKBONE_CFG:
     dwp = torch.zeros((co, k, k, ci), dtype=torch.float32, device=dev)
     db = torch.zeros((co,), dtype=torch.float32, device=dev)
     tiles = ((co + 127) // 128) * ((ci + 127) // 128) * k * k
-    for split in sorted(set([max(1, min(dy.slots // 256, (1024 + tiles - 1) // tiles)), max(1, (256 + tiles - 1) // tiles), max(1, (512 + tiles - 1) // tiles)])):
-        wd = WgradDesc(dy.slots, dy.px_stride, x.px_stride, co, ci, k, k, p, x.row_stride, split, 0)
+    for split in (SPLITS or sorted(set([max(1, min(dy.slots // 256, (1024 + tiles - 1) // tiles)), max(1, (256 + tiles - 1) // tiles), max(1, (512 + tiles - 1) // tiles)]))):
+        wd = WgradDesc(dy.slots, dy.px_stride, x.px_stride, co, ci, k, k, p, x.row_stride, split, 0, VARIANT)
         def run(w, b):
             check(lib().yolo_wgrad(ctypes.byref(wd), x.p, dy.p, ptr(w) if w is not None else None, ptr(b) if b is not None else None, stream()))
         res = []

@@ -18,6 +18,7 @@
 // Replaces the weight-gradient half of aten convolution_backward / addmm backward for
 // src/yolo/models.py:47-84,239-245,313-332.
 #include <algorithm>
+#include <type_traits>
 
 #include "common.h"
 
@@ -42,16 +43,111 @@ struct WgradParams {
     long x_row_stride;
     int n_co_tiles, n_ci_tiles, ntaps;
     int atomic;
+    // two-segment schedule (seg = 1, 1-D grid): the first main_tiles tiles are split into main_split pixel ranges and fill
+    // whole rounds of the chip's 512 workgroup slots; the remaining tail_tiles (< 512 / main_split) tiles are split finer
+    // (tail_split ranges) so that they fill one more, shorter round instead of leaving most CUs idle for a full-length one
+    int seg;
+    int main_tiles, main_split, tail_tiles, tail_split;
+    long per_main, per_tail;
 };
+
+constexpr int WG_SLOTS = 512;   // 256 CUs x 2 resident workgroups (64 KB of LDS each)
+
+// workgroup -> (logical tile id, first pixel, pixels).  Hardware hands consecutive workgroup ids to the 8 XCDs round-robin;
+// within every group of 512 ids an XCD gets 64 CONSECUTIVE logical workgroups: same pixel range, neighbouring tiles
+// (co fastest), so the dy / x rows they stream are shared through that XCD's L2.
+__device__ __forceinline__ void wgrad_map(const WgradParams &p, int nwg, int &bid, long &pbeg, long &pend)
+{
+    if (p.seg) {
+        const int id = blockIdx.x;
+        const int L = (id & ~(WG_SLOTS - 1)) | ((id & 7) << 6) | ((id >> 3) & 63);
+        const int nmain = p.main_tiles * p.main_split;
+        int range;
+        long per;
+        if (L < nmain) {
+            const int tpr = WG_SLOTS / p.main_split;          // tiles per round
+            const int round = L / WG_SLOTS, within = L % WG_SLOTS;
+            range = within / tpr;
+            bid = round * tpr + within % tpr;
+            per = p.per_main;
+        } else {
+            const int t = L - nmain, tt = max(p.tail_tiles, 1);
+            range = p.tail_tiles > 0 ? t / tt : p.tail_split;   // no tail: past every range -> empty
+            bid = p.main_tiles + t % tt;
+            per = p.per_tail;
+        }
+        pbeg = (long)range * per;
+        pend = min(p.P, pbeg + per);
+        if (bid >= nwg) pend = pbeg;   // ids past the last logical workgroup (grid rounded up to the XCD map)
+    } else {
+        const int q = nwg >> 3, r = nwg & 7, xcd = blockIdx.x & 7, k = blockIdx.x >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+        pbeg = (long)blockIdx.y * p.p_per_split;
+        pend = min(p.P, pbeg + p.p_per_split);
+    }
+}
 
 #define GLDS16(gptr, lptr) \
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gptr), (__attribute__((address_space(3))) void *)(lptr), 16, 0, 0)
+
+// the same instruction from inline asm, invisible to the compiler's LDS alias / waitcnt tracking (wgrad256_kernel);
+// lds = wave-uniform LDS byte address of the wave's 1-KB destination
+#define DMA16(gptr, lds) \
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gptr), "s"(lds) : "memory", "m0")
 
 constexpr int WG_T = 128;                 // tile edge (co and ci)
 constexpr int WG_BP = 64;                 // pixels per K step
 constexpr int WG_TILE_BYTES = WG_BP * WG_T * 2;   // 16 KB
 constexpr int WG_STAGE_BYTES = 2 * WG_TILE_BYTES; // dy + x
 constexpr int WG_LDS_BYTES = 2 * WG_STAGE_BYTES;  // double buffered: 64 KB
+
+typedef __attribute__((address_space(3))) s16x4 *lds_s16x4;
+
+struct WFrag {
+    bf16x8 a[2], b[2];
+};
+
+// fragments of one 16-pixel sub-step: 4 + 4 transposing reads (rows +4 lie `a_hi` / `b_hi` bytes further)
+template <bool BIAS>
+__device__ __forceinline__ void wave_load(const char *sb, const int (&a_rd)[2], const int (&b_rd)[2], int a_off, int a_hi, int b_off, int b_hi, WFrag &f,
+                                          float (&bsum)[2])
+{
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(sb + a_rd[t] + a_off));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(sb + a_rd[t] + a_off + a_hi));
+        f.a[t] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+        if (BIAS) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) bsum[t] += __uint_as_float(((unsigned)(unsigned short)lo[e]) << 16) + __uint_as_float(((unsigned)(unsigned short)hi[e]) << 16);
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(sb + b_rd[t] + b_off));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(sb + b_rd[t] + b_off + b_hi));
+        f.b[t] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+    }
+}
+
+// one 64-pixel K step of a wave's 64 x 64 tile, software-pipelined: the reads of sub-step ks+1 are issued in front of
+// the MFMAs of sub-step ks.  BIAS is a template flag and the caller branches ONCE per workgroup: a per-lane `if` inside
+// this loop splits it into basic blocks and the compiler then waits lgkmcnt(0) in front of every MFMA group.
+template <bool BIAS, int A_KS, int A_HI, int B_KS, int B_HI>
+__device__ __forceinline__ void wave_step(const char *sb, const int (&a_rd)[2], const int (&b_rd)[2], f32x16 (&acc)[2][2], float (&bsum)[2])
+{
+    WFrag cur, nxt;
+    wave_load<BIAS>(sb, a_rd, b_rd, 0, A_HI, 0, B_HI, cur, bsum);
+#pragma unroll
+    for (int ks = 0; ks < WG_BP / 16; ++ks) {
+        if (ks + 1 < WG_BP / 16) wave_load<BIAS>(sb, a_rd, b_rd, (ks + 1) * A_KS, A_HI, (ks + 1) * B_KS, B_HI, nxt, bsum);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur.a[i], cur.b[j], acc[i][j], 0, 0, 0);
+        cur = nxt;
+    }
+}
 
 __global__ void __launch_bounds__(256, 2) wgrad_kernel(const WgradParams p)
 {
@@ -65,13 +161,11 @@ __global__ void __launch_bounds__(256, 2) wgrad_kernel(const WgradParams p)
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wco = wave >> 1, wci = wave & 1;
 
-    // XCD-aware remap (see igemm.hip): contiguous logical tiles per XCD
     const int nwg = p.n_co_tiles * p.n_ci_tiles * p.ntaps;
-    int bid = blockIdx.x;
-    {
-        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, k = bid >> 3;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
-    }
+    int bid;
+    long pbeg, pend;
+    wgrad_map(p, nwg, bid, pbeg, pend);
+    if (pbeg >= pend) return;   // empty range of a rounded-up split (the whole workgroup leaves)
     // co-tile fastest, then ci-tile, then tap: neighbours share the x tile of one tap
     const int co_tile = bid % p.n_co_tiles;
     const int rest = bid / p.n_co_tiles;
@@ -81,8 +175,6 @@ __global__ void __launch_bounds__(256, 2) wgrad_kernel(const WgradParams p)
     const long tap_off = (long)(ky - p.pad) * p.x_row_stride + (long)(kx - p.pad) * p.x_px_stride;
     const int co0 = co_tile * WG_T, ci0 = ci_tile * WG_T;
 
-    const long pbeg = (long)blockIdx.y * p.p_per_split;
-    const long pend = min(p.P, pbeg + p.p_per_split);
 
     // ---- LDS-DMA sources.  A wave-instruction covers 4 pixel rows x 256 B.  Slot (row, c') holds
     // data chunk c = c' ^ ((row&3)<<2): the transposing reads of one 32-lane half then touch 16
@@ -139,45 +231,23 @@ __global__ void __launch_bounds__(256, 2) wgrad_kernel(const WgradParams p)
     const bool do_bias = p.db != nullptr && tap == 0 && ci_tile == 0 && wci == 0;
     float bsum[2] = {0.0f, 0.0f};
 
-    typedef __attribute__((address_space(3))) s16x4 *lds_s16x4;
-    auto compute = [&](const char *sb) {
-#pragma unroll
-        for (int ks = 0; ks < WG_BP / 16; ++ks) {
-            bf16x8 af[2], bfr[2];
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(sb + a_rd[t] + ks * 4096));
-                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(sb + a_rd[t] + ks * 4096 + 1024));
-                af[t] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
-                if (do_bias) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) bsum[t] += __uint_as_float(((unsigned)(unsigned short)lo[e]) << 16) + __uint_as_float(((unsigned)(unsigned short)hi[e]) << 16);
-                }
-            }
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(sb + b_rd[t] + ks * 4096));
-                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(sb + b_rd[t] + ks * 4096 + 1024));
-                bfr[t] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
-            }
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+    auto run = [&](auto bias_tag) {
+        constexpr bool BIAS = decltype(bias_tag)::value;
+        if (pbeg < pend) stage(bufA, pbeg);
+        for (long pb = pbeg; pb < pend; pb += 2 * WG_BP) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();  // stage A landed for every wave; stage B is free
+            if (pb + WG_BP < pend) stage(bufB, pb + WG_BP);
+            wave_step<BIAS, 4096, 1024, 4096, 1024>(bufA, a_rd, b_rd, acc, bsum);
+            if (pb + WG_BP >= pend) break;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (pb + 2 * WG_BP < pend) stage(bufA, pb + 2 * WG_BP);
+            wave_step<BIAS, 4096, 1024, 4096, 1024>(bufB, a_rd, b_rd, acc, bsum);
         }
     };
-    if (pbeg < pend) stage(bufA, pbeg);
-    for (long pb = pbeg; pb < pend; pb += 2 * WG_BP) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();  // stage A landed for every wave; stage B is free
-        if (pb + WG_BP < pend) stage(bufB, pb + WG_BP);
-        compute(bufA);
-        if (pb + WG_BP >= pend) break;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (pb + 2 * WG_BP < pend) stage(bufA, pb + 2 * WG_BP);
-        compute(bufB);
-    }
+    if (do_bias) run(std::true_type{});
+    else run(std::false_type{});
 
     if (do_bias) {
 #pragma unroll
@@ -190,6 +260,164 @@ __global__ void __launch_bounds__(256, 2) wgrad_kernel(const WgradParams p)
 
     // ---- output: D row (= co) = (reg&3) + 8*(reg>>2) + 4*(lane>>5), col (= ci) = lane&31.
     // Per register the 32 lanes of a half write 128 contiguous bytes of one dw row.
+    const long ldw = (long)p.ntaps * p.Cin;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int ci = ci0 + wci * 64 + j * 32 + (lane & 31);
+            if (ci >= p.Cin) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = co0 + wco * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (co >= p.Cout) continue;
+                float *o = p.dw + (long)co * ldw + (long)tap * p.Cin + ci;
+                if (p.atomic) atomicAdd(o, acc[i][j][r]);
+                else *o = acc[i][j][r];
+            }
+        }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// 256 co x 128 ci variant, 8 waves (4 x 2, the same 64 x 64 wave tile), THREE 48-KB stages.
+// The 128 x 128 kernel above keeps at most one 32-KB stage per workgroup in flight (two workgroups per
+// CU): a K step computes for ~0.45 us while a stage takes 1.5-2 us to arrive, so the loop runs at the
+// LDS-DMA latency, not at the MFMA rate (measured 31 % of peak on the 3x3 layers).  Here two stages
+// (96 KB per CU) are in flight behind the one being consumed and every byte staged feeds twice the
+// MFMA work; waits are counted (vmcnt(6) = "everything but the newest stage") and the barrier is the
+// raw s_barrier, so a wave never drains the queue.  One static LDS array per stage + a loop unrolled by
+// three keep every access's stage static (see the note in wgrad_kernel).
+constexpr int W2_TCO = 256, W2_TCI = 128;
+constexpr int W2_A_BYTES = WG_BP * W2_TCO * 2;     // 32 KB
+constexpr int W2_B_BYTES = WG_BP * W2_TCI * 2;     // 16 KB
+constexpr int W2_STAGE = W2_A_BYTES + W2_B_BYTES;  // 48 KB
+
+__global__ void __launch_bounds__(512, 1) wgrad256_kernel(const WgradParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // 3 stages x 48 KB
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char *)smem;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wco = wave >> 1, wci = wave & 1;
+
+    const int nwg = p.n_co_tiles * p.n_ci_tiles * p.ntaps;
+    int bid;
+    long pbeg, pend;
+    wgrad_map(p, nwg, bid, pbeg, pend);
+    if (pbeg >= pend) return;   // empty range of a rounded-up split (the whole workgroup leaves)
+    const int co_tile = bid % p.n_co_tiles;
+    const int rest = bid / p.n_co_tiles;
+    const int ci_tile = rest % p.n_ci_tiles;
+    const int tap = rest / p.n_ci_tiles;
+    const int ky = tap / p.KW, kx = tap - ky * p.KW;
+    const long tap_off = (long)(ky - p.pad) * p.x_row_stride + (long)(kx - p.pad) * p.x_px_stride;
+    const int co0 = co_tile * W2_TCO, ci0 = ci_tile * W2_TCI;
+
+
+    // ---- LDS-DMA sources: dy rows are 512 B (2 pixel rows per wave-instruction), x rows 256 B (4 per instruction);
+    // slot (row, c') holds chunk c = c' ^ ((row&3)<<2) in both (see wgrad_kernel)
+    int a_row[4], a_coff[4], b_row[2], b_coff[2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int pos = (i * 8 + wave) * 64 + lane;
+        const int row = pos >> 5, cs = pos & 31;
+        int ca = co0 / 8 + (cs ^ ((row & 3) << 2));
+        if (ca >= p.Cout_ld / 8) ca = p.Cout_ld / 8 - 1;
+        a_row[i] = row;
+        a_coff[i] = ca * 8;
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int pos = (i * 8 + wave) * 64 + lane;
+        const int row = pos >> 4, cs = pos & 15;
+        int cb = ci0 / 8 + (cs ^ ((row & 3) << 2));
+        if (cb >= p.Cin_ld / 8) cb = p.Cin_ld / 8 - 1;
+        b_row[i] = row;
+        b_coff[i] = cb * 8;
+    }
+    const bf16_t *zline = reinterpret_cast<const bf16_t *>(g_zero_line) + (lane & 15) * 8;
+
+    auto stage = [&](int st, long pb) {
+        const unsigned sb = lds0 + st * W2_STAGE;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const long pr = pb + a_row[i];
+            const bf16_t *sa = pr < pend ? p.dy + pr * p.dy_px_stride + a_coff[i] : zline;
+            DMA16(sa, sb + (i * 8 + wave) * 1024);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const long pr = pb + b_row[i];
+            const bf16_t *sx = pr < pend ? p.x + pr * p.x_px_stride + tap_off + b_coff[i] : zline;
+            DMA16(sx, sb + W2_A_BYTES + (i * 8 + wave) * 1024);
+        }
+    };
+
+    const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
+    int a_rd[2], b_rd[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int row = (g >> 1) * 8 + q;
+        const int ca = (wco * 64 + t * 32 + (g & 1) * 16 + 4 * pp) >> 3;
+        const int cb = (wci * 64 + t * 32 + (g & 1) * 16 + 4 * pp) >> 3;
+        a_rd[t] = row * 512 + ((ca ^ ((row & 3) << 2)) << 4) + (pp & 1) * 8;
+        b_rd[t] = W2_A_BYTES + row * 256 + ((cb ^ ((row & 3) << 2)) << 4) + (pp & 1) * 8;
+    }
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    const bool do_bias = p.db != nullptr && tap == 0 && ci_tile == 0 && wci == 0;
+    float bsum[2] = {0.0f, 0.0f};
+
+    // The LDS-DMA is issued from inline asm (DMA16): hipcc's own waitcnt pass otherwise drains vmcnt(0) in front of the
+    // first transposing read of every loop iteration (it cannot bound the age of the stage being read across the
+    // back-edge), which empties the pipeline every third step.  So ordering is all explicit here: wait until only the
+    // newest stage (6 instructions per wave) may still be in flight, meet the other waves, and fence the compiler.
+#define W2_SYNC(more)                                                 \
+    do {                                                              \
+        if (more) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");    \
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         \
+        __builtin_amdgcn_s_barrier();                                 \
+        asm volatile("" ::: "memory");                                \
+    } while (0)
+
+    const long nsteps = pbeg < pend ? (pend - pbeg + WG_BP - 1) / WG_BP : 0;
+    auto run = [&](auto bias_tag) {
+        constexpr bool BIAS = decltype(bias_tag)::value;
+        if (nsteps > 0) stage(0, pbeg);
+        if (nsteps > 1) stage(1, pbeg + WG_BP);
+        for (long t = 0; t < nsteps; t += 3) {
+            W2_SYNC(t + 1 < nsteps);
+            if (t + 2 < nsteps) stage(2, pbeg + (t + 2) * WG_BP);
+            wave_step<BIAS, 8192, 2048, 4096, 1024>(smem, a_rd, b_rd, acc, bsum);
+            if (t + 1 >= nsteps) break;
+            W2_SYNC(t + 2 < nsteps);
+            if (t + 3 < nsteps) stage(0, pbeg + (t + 3) * WG_BP);
+            wave_step<BIAS, 8192, 2048, 4096, 1024>(smem + W2_STAGE, a_rd, b_rd, acc, bsum);
+            if (t + 2 >= nsteps) break;
+            W2_SYNC(t + 3 < nsteps);
+            if (t + 4 < nsteps) stage(1, pbeg + (t + 4) * WG_BP);
+            wave_step<BIAS, 8192, 2048, 4096, 1024>(smem + 2 * W2_STAGE, a_rd, b_rd, acc, bsum);
+        }
+    };
+    if (do_bias) run(std::true_type{});
+    else run(std::false_type{});
+#undef W2_SYNC
+
+    if (do_bias) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const float tot = bsum[t] + __shfl_xor(bsum[t], 32, 64);
+            const int co = co0 + wco * 64 + t * 32 + (lane & 31);
+            if (lane < 32 && co < p.Cout) atomicAdd(p.db + co, tot);
+        }
+    }
     const long ldw = (long)p.ntaps * p.Cin;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -443,7 +671,7 @@ YOLO_API int yolo_wgrad_stem7(const void *x_nhwc4, const void *dy, int N, int Ho
 YOLO_API int yolo_wgrad(const yolo_wgrad_desc *d, const void *x, const void *dy, float *dw, float *db, yolo_stream_t stream)
 {
     if (!d || !x || !dy || (!dw && !db)) return fail(YOLO_E_ARG, "yolo_wgrad: null pointer");
-    if (d->P <= 0 || d->Cout <= 0 || d->Cin <= 0 || d->KH <= 0 || d->KW <= 0 || d->split <= 0) return fail(YOLO_E_ARG, "yolo_wgrad: bad descriptor");
+    if (d->P <= 0 || d->Cout <= 0 || d->Cin <= 0 || d->KH <= 0 || d->KW <= 0 || d->split < 0) return fail(YOLO_E_ARG, "yolo_wgrad: bad descriptor");
     if ((d->dy_px_stride & 7) || (d->x_px_stride & 7) || (d->x_row_stride & 7) || d->dy_px_stride < d->Cout || d->x_px_stride < d->Cin)
         return fail(YOLO_E_UNSUPPORTED, "yolo_wgrad: pixel strides must be multiples of 8 elements and cover the channels");
     hipStream_t s = STRM(stream);
@@ -456,15 +684,62 @@ YOLO_API int yolo_wgrad(const yolo_wgrad_desc *d, const void *x, const void *dy,
         p.Cout_ld = (int)((std::min<long>(d->dy_px_stride, ((long)d->Cout + 7) & ~7L)));
         p.Cin_ld = (int)((std::min<long>(d->x_px_stride, ((long)d->Cin + 7) & ~7L)));
         p.KH = d->KH; p.KW = d->KW; p.pad = d->pad; p.x_row_stride = d->x_row_stride;
-        p.n_co_tiles = (d->Cout + WG_T - 1) / WG_T;
         p.n_ci_tiles = (d->Cin + WG_T - 1) / WG_T;
         p.ntaps = d->KH * d->KW;
-        long per = (d->P + d->split - 1) / d->split;
-        per = (per + WG_BP - 1) / WG_BP * WG_BP;
-        const int splits = (int)((d->P + per - 1) / per);
-        p.p_per_split = per;
-        p.atomic = (splits > 1 || d->accumulate) ? 1 : 0;
-        hipLaunchKernelGGL(wgrad_kernel, dim3(p.n_co_tiles * p.n_ci_tiles * p.ntaps, splits), dim3(256), 0, s, p);
+        const long steps_total = (d->P + WG_BP - 1) / WG_BP;
+        // kernel variant: 256-wide co tiles (8 waves, 3 stages) only on request (d->variant == 2): measured no faster
+        // than two co-resident 128 x 128 workgroups on any layer of the model
+        const bool big = d->variant == 2;
+        p.n_co_tiles = big ? (d->Cout + W2_TCO - 1) / W2_TCO : (d->Cout + WG_T - 1) / WG_T;
+        const int tiles = p.n_co_tiles * p.n_ci_tiles * p.ntaps;
+        dim3 grid;
+        if (d->split > 0) {
+            // uniform split, 2-D grid (tiles x ranges)
+            long per = (d->P + d->split - 1) / d->split;
+            per = (per + WG_BP - 1) / WG_BP * WG_BP;
+            const int splits = (int)((d->P + per - 1) / per);
+            p.p_per_split = per;
+            p.atomic = (splits > 1 || d->accumulate) ? 1 : 0;
+            grid = dim3((unsigned)tiles, (unsigned)splits);
+        } else {
+            // split == 0: two-segment schedule (see WgradParams), dw is accumulated.  Cost model in K steps: a round of
+            // workgroups costs its K steps + ~30 steps' worth of prologue and atomic epilogue (fitted on the 3x3 layers).
+            const int slots = big ? WG_SLOTS / 2 : WG_SLOTS;
+            const double E = 30.0;
+            double best = 1e30;
+            int bs = 1, bt = 1;
+            for (int sp = 1; sp <= slots; sp *= 2) {
+                if (sp > 1 && steps_total / sp < 4) break;
+                const int tpr = slots / sp;
+                const int mt = tiles / tpr * tpr, tt = tiles - mt;
+                long ts = 1;
+                if (tt > 0) ts = std::max<long>(sp, std::min<long>(slots / tt, std::max<long>(1, steps_total / 4)));
+                const double cost = (double)(mt / tpr) * ((double)((steps_total + sp - 1) / sp) + E) + (tt > 0 ? (double)((steps_total + ts - 1) / ts) + E : 0.0);
+                if (cost < best) { best = cost; bs = sp; bt = (int)ts; }
+            }
+            const int tpr = slots / bs;
+            p.seg = 1;
+            p.main_split = bs;
+            p.main_tiles = tiles / tpr * tpr;
+            p.tail_tiles = tiles - p.main_tiles;
+            p.tail_split = p.tail_tiles > 0 ? bt : 1;
+            p.per_main = ((d->P + bs - 1) / bs + WG_BP - 1) / WG_BP * WG_BP;
+            p.per_tail = ((d->P + p.tail_split - 1) / p.tail_split + WG_BP - 1) / WG_BP * WG_BP;
+            p.atomic = 1;
+            const long nblk = (long)p.main_tiles * bs + (long)p.tail_tiles * p.tail_split;
+            grid = dim3((unsigned)((nblk + WG_SLOTS - 1) / WG_SLOTS * WG_SLOTS));   // whole groups of 512 ids for the XCD map
+        }
+        if (big) {
+            static bool lds_ok = false;
+            if (!lds_ok) {
+                hipError_t e = hipFuncSetAttribute((const void *)wgrad256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * W2_STAGE);
+                if (e != hipSuccess) return fail((int)e, "yolo_wgrad: hipFuncSetAttribute(%d B LDS): %s", 3 * W2_STAGE, hipGetErrorString(e));
+                lds_ok = true;
+            }
+            hipLaunchKernelGGL(wgrad256_kernel, grid, dim3(512), 3 * W2_STAGE, s, p);
+        } else {
+            hipLaunchKernelGGL(wgrad_kernel, grid, dim3(256), 0, s, p);
+        }
         if (int rc = check_launch("yolo_wgrad")) return rc;
     }
     if (db && !dw) {

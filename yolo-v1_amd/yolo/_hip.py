@@ -49,7 +49,7 @@ class WgradDesc(ctypes.Structure):
         ("Cout", ctypes.c_int32), ("Cin", ctypes.c_int32),
         ("KH", ctypes.c_int32), ("KW", ctypes.c_int32), ("pad", ctypes.c_int32),
         ("x_row_stride", ctypes.c_int64),
-        ("split", ctypes.c_int32), ("accumulate", ctypes.c_int32),
+        ("split", ctypes.c_int32), ("accumulate", ctypes.c_int32), ("variant", ctypes.c_int32),
     ]
 
 

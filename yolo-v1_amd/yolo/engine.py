@@ -769,9 +769,7 @@ class Plan:
                         check(L_.yolo_wgrad(ctypes.byref(wd), xcol.p, g.p, ptr(dwp), ptr(db), st), "wgrad conv0")
                 else:
                     dwp = scratch[o: o + L.Cout * L.K * L.K * L.Cin]
-                    tiles = ((L.Cout + 127) // 128) * ((L.Cin + 127) // 128) * L.K * L.K
-                    split = max(1, min(g.slots // 256, (1024 + tiles - 1) // tiles))
-                    wd = WgradDesc(g.slots, g.px_stride, xin.px_stride, L.Cout, L.Cin, L.K, L.K, L.pad, xin.row_stride, split, 0)
+                    wd = WgradDesc(g.slots, g.px_stride, xin.px_stride, L.Cout, L.Cin, L.K, L.K, L.pad, xin.row_stride, 0, 0)   # split: library's choice
                     with _timed(f"conv{li}.wgrad", "wgrad", 2.0 * N * L.Hout * L.Wout * L.Cout * L.Cin * L.K * L.K):
                         check(L_.yolo_wgrad(ctypes.byref(wd), xin.p, g.p, ptr(dwp), ptr(db), st), f"wgrad conv{li}")
                 if not stem_direct:
