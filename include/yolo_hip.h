@@ -175,6 +175,13 @@ typedef struct yolo_wgrad_desc {
     int32_t accumulate;              /* 1: add into dw even when split == 1                       */
     int32_t variant;                 /* 0: choose; 1: 128x128 tile, 4 waves, 2 stages; 2: 256x128 tile,
                                         8 waves, 3 stages (tests / tuning)                        */
+    /* Pixel geometry (geo_W == 0: "flat" indexing, p IS the slot).  Otherwise the reduction runs over the P = N*geo_H*geo_W
+     * pixels p = (n*geo_H + oy)*geo_W + ox only, and pixel p lives in slot
+     *     n*geo_img_slots + oy*geo_row_slots + ox*geo_px_slots + geo_slot0
+     * of BOTH buffers (dy at slot*dy_px_stride, x at slot*x_px_stride + tap offset): the interior of a zero-haloed buffer
+     * (geo_px_slots = 1) skips the halo slots -- 1.04x .. 1.65x fewer K steps -- and geo_px_slots = 2 with
+     * geo_row_slots = 2 * row pitch visits only the non-zero slots of a stride-2 conv's zero-stuffed gradient (4x fewer). */
+    int32_t geo_W, geo_H, geo_img_slots, geo_row_slots, geo_px_slots, geo_slot0;
 } yolo_wgrad_desc;
 
 int yolo_wgrad(const yolo_wgrad_desc *d, const void *x_bf16, const void *dy_bf16,

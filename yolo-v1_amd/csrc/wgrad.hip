@@ -35,7 +35,12 @@ struct WgradParams {
     const bf16_t *dy;
     float *dw;
     float *db;              // optional: bias gradient, accumulated by the (tap 0, ci-tile 0) workgroups
-    long P;                 // flat pixel slots to reduce over
+    long P;                 // pixels to reduce over
+    // pixel p -> slot in the dy / x buffers.  gW == 0: p is the slot ("flat" indexing).  Else p = (n*gH + oy)*gW + ox and
+    // slot = n*g_img + oy*g_row + ox*g_px + g_off (interior pixels of a zero-haloed buffer, optionally every 2nd one);
+    // mW, mH = ceil(2^32 / gW), ceil(2^32 / gH) turn the small divisions into v_mul_hi_u32
+    int gW, gH, g_img, g_row, g_px, g_off;
+    unsigned mW, mH;
     long p_per_split;
     int dy_px_stride, x_px_stride;
     int Cout, Cin, Cout_ld, Cin_ld;  // logical sizes and loadable (multiple-of-8) widths
@@ -194,15 +199,47 @@ __global__ void __launch_bounds__(256, 2) wgrad_kernel(const WgradParams p)
     }
     const bf16_t *zline = reinterpret_cast<const bf16_t *>(g_zero_line) + (lane & 15) * 8;
 
+    // slot[i]: buffer slot of the lane's i-th pixel row in the NEXT stage to be issued (-1: past the range -> zeros).
+    // With a pixel index the lookups for stage t+1 are issued right behind the LDS-DMA of stage t and have a whole K
+    // step to arrive.
+    // (n0, oy0, ox0) = pixel coordinates of the first row of the NEXT stage to issue, carried in scalars; a lane's rows lie
+    // < 64 pixels further, so their coordinates follow with two multiply-high "small divisions" each -- no index table, no
+    // extra memory instruction (a table cost 7-17 % on the 56x56 / 112x112 layers, whichever way it was read).
+    int n0 = 0, oy0 = 0, ox0 = 0;
+    if (p.gW) {
+        const long row = pbeg / p.gW;
+        ox0 = (int)(pbeg - row * p.gW);
+        n0 = (int)(row / p.gH);
+        oy0 = (int)(row - (long)n0 * p.gH);
+    }
     auto stage = [&](char *sb, long pb) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const long pr = pb + row_of[i];
+            long slot;
+            if (p.gW) {
+                const unsigned a = (unsigned)(ox0 + row_of[i]);
+                const unsigned qx = __umulhi(a, p.mW);
+                const unsigned b = (unsigned)oy0 + qx;
+                const unsigned qy = __umulhi(b, p.mH);
+                slot = (long)(n0 + (int)qy) * p.g_img + (int)(b - qy * p.gH) * p.g_row + (int)(a - qx * p.gW) * p.g_px + p.g_off;
+            } else {
+                slot = pr;
+            }
             const bool ok = pr < pend;
-            const bf16_t *sa = ok ? p.dy + pr * p.dy_px_stride + a_coff[i] : zline;
-            const bf16_t *sx = ok ? p.x + pr * p.x_px_stride + tap_off + b_coff[i] : zline;
+            const bf16_t *sa = ok ? p.dy + slot * p.dy_px_stride + a_coff[i] : zline;
+            const bf16_t *sx = ok ? p.x + slot * p.x_px_stride + tap_off + b_coff[i] : zline;
             GLDS16(sa, sb + (i * 4 + wave) * 1024);
             GLDS16(sx, sb + WG_TILE_BYTES + (i * 4 + wave) * 1024);
+        }
+        if (p.gW) {   // advance the scalar coordinates by one stage (64 pixels)
+            const unsigned a = (unsigned)(ox0 + WG_BP);
+            const unsigned qx = __umulhi(a, p.mW);
+            const unsigned b = (unsigned)oy0 + qx;
+            const unsigned qy = __umulhi(b, p.mH);
+            ox0 = (int)(a - qx * p.gW);
+            oy0 = (int)(b - qy * p.gH);
+            n0 += (int)qy;
         }
     };
 
@@ -233,7 +270,7 @@ __global__ void __launch_bounds__(256, 2) wgrad_kernel(const WgradParams p)
 
     auto run = [&](auto bias_tag) {
         constexpr bool BIAS = decltype(bias_tag)::value;
-        if (pbeg < pend) stage(bufA, pbeg);
+        stage(bufA, pbeg);
         for (long pb = pbeg; pb < pend; pb += 2 * WG_BP) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();  // stage A landed for every wave; stage B is free
@@ -679,6 +716,17 @@ YOLO_API int yolo_wgrad(const yolo_wgrad_desc *d, const void *x, const void *dy,
         WgradParams p{};
         p.x = (const bf16_t *)x; p.dy = (const bf16_t *)dy; p.dw = dw; p.db = db;
         p.P = d->P;
+        if (d->geo_W < 0 || d->geo_H < 0 || (d->geo_W > 0 && (d->geo_H <= 0 || d->geo_W > 65536 || d->geo_H > 65536)))
+            return fail(YOLO_E_ARG, "yolo_wgrad: bad pixel geometry %d x %d", d->geo_W, d->geo_H);
+        if (d->geo_W > 0) {
+            if (d->variant == 2) return fail(YOLO_E_UNSUPPORTED, "yolo_wgrad: variant 2 has no pixel-geometry mode");
+            if (d->P % ((long)d->geo_W * d->geo_H)) return fail(YOLO_E_ARG, "yolo_wgrad: P = %ld is not a whole number of %d x %d images", (long)d->P, d->geo_W, d->geo_H);
+            p.gW = d->geo_W; p.gH = d->geo_H;
+            p.g_img = d->geo_img_slots; p.g_row = d->geo_row_slots; p.g_px = d->geo_px_slots; p.g_off = d->geo_slot0;
+            p.mW = (unsigned)(((1ull << 32) + d->geo_W - 1) / d->geo_W);   // 2^32 for W = 1 wraps to 0: handled by W == 1 -> q = a
+            p.mH = (unsigned)(((1ull << 32) + d->geo_H - 1) / d->geo_H);
+            if (d->geo_W == 1 || d->geo_H == 1) return fail(YOLO_E_UNSUPPORTED, "yolo_wgrad: pixel geometry needs W, H >= 2 (use flat indexing)");
+        }
         p.dy_px_stride = d->dy_px_stride; p.x_px_stride = d->x_px_stride;
         p.Cout = d->Cout; p.Cin = d->Cin;
         p.Cout_ld = (int)((std::min<long>(d->dy_px_stride, ((long)d->Cout + 7) & ~7L)));

@@ -50,6 +50,8 @@ class WgradDesc(ctypes.Structure):
         ("KH", ctypes.c_int32), ("KW", ctypes.c_int32), ("pad", ctypes.c_int32),
         ("x_row_stride", ctypes.c_int64),
         ("split", ctypes.c_int32), ("accumulate", ctypes.c_int32), ("variant", ctypes.c_int32),
+        ("geo_W", ctypes.c_int32), ("geo_H", ctypes.c_int32), ("geo_img_slots", ctypes.c_int32), ("geo_row_slots", ctypes.c_int32),
+        ("geo_px_slots", ctypes.c_int32), ("geo_slot0", ctypes.c_int32),
     ]
 
 
