@@ -171,7 +171,8 @@ typedef struct yolo_wgrad_desc {
     int64_t x_row_stride;            /* elements between input rows (multiple of 8)               */
     int32_t split;                   /* pixel-range split (uniform, 2-D grid).  0: the library's two-segment
                                         schedule -- whole rounds of the chip's workgroup slots plus a finer-split
-                                        tail round; dw is then ALWAYS accumulated (caller zero-fills) */
+                                        tail round; the caller zero-fills dw (tiles that are split over
+                                        several workgroups are accumulated with atomics, the others stored) */
     int32_t accumulate;              /* 1: add into dw even when split == 1                       */
     int32_t variant;                 /* 0: choose; 1: 128x128 tile, 4 waves, 2 stages; 2: 256x128 tile,
                                         8 waves, 3 stages (tests / tuning)                        */

@@ -47,7 +47,7 @@ struct WgradParams {
     int KH, KW, pad;
     long x_row_stride;
     int n_co_tiles, n_ci_tiles, ntaps;
-    int atomic;
+    int atomic;             // uniform split: accumulate with atomics.  Two-segment schedule: bit 0 = main segment, bit 1 = tail
     // two-segment schedule (seg = 1, 1-D grid): the first main_tiles tiles are split into main_split pixel ranges and fill
     // whole rounds of the chip's 512 workgroup slots; the remaining tail_tiles (< 512 / main_split) tiles are split finer
     // (tail_split ranges) so that they fill one more, shorter round instead of leaving most CUs idle for a full-length one
@@ -61,8 +61,9 @@ constexpr int WG_SLOTS = 512;   // 256 CUs x 2 resident workgroups (64 KB of LDS
 // workgroup -> (logical tile id, first pixel, pixels).  Hardware hands consecutive workgroup ids to the 8 XCDs round-robin;
 // within every group of 512 ids an XCD gets 64 CONSECUTIVE logical workgroups: same pixel range, neighbouring tiles
 // (co fastest), so the dy / x rows they stream are shared through that XCD's L2.
-__device__ __forceinline__ void wgrad_map(const WgradParams &p, int nwg, int &bid, long &pbeg, long &pend)
+__device__ __forceinline__ void wgrad_map(const WgradParams &p, int nwg, int &bid, long &pbeg, long &pend, bool &atomic)
 {
+    atomic = p.atomic & 1;
     if (p.seg) {
         const int id = blockIdx.x;
         const int L = (id & ~(WG_SLOTS - 1)) | ((id & 7) << 6) | ((id >> 3) & 63);
@@ -80,6 +81,7 @@ __device__ __forceinline__ void wgrad_map(const WgradParams &p, int nwg, int &bi
             range = p.tail_tiles > 0 ? t / tt : p.tail_split;   // no tail: past every range -> empty
             bid = p.main_tiles + t % tt;
             per = p.per_tail;
+            atomic = (p.atomic >> 1) & 1;
         }
         pbeg = (long)range * per;
         pend = min(p.P, pbeg + per);
@@ -169,7 +171,8 @@ __global__ void __launch_bounds__(256, 2) wgrad_kernel(const WgradParams p)
     const int nwg = p.n_co_tiles * p.n_ci_tiles * p.ntaps;
     int bid;
     long pbeg, pend;
-    wgrad_map(p, nwg, bid, pbeg, pend);
+    bool atomic;
+    wgrad_map(p, nwg, bid, pbeg, pend, atomic);
     if (pbeg >= pend) return;   // empty range of a rounded-up split (the whole workgroup leaves)
     // co-tile fastest, then ci-tile, then tap: neighbours share the x tile of one tap
     const int co_tile = bid % p.n_co_tiles;
@@ -309,7 +312,7 @@ __global__ void __launch_bounds__(256, 2) wgrad_kernel(const WgradParams p)
                 const int co = co0 + wco * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                 if (co >= p.Cout) continue;
                 float *o = p.dw + (long)co * ldw + (long)tap * p.Cin + ci;
-                if (p.atomic) atomicAdd(o, acc[i][j][r]);
+                if (atomic) atomicAdd(o, acc[i][j][r]);
                 else *o = acc[i][j][r];
             }
         }
@@ -340,7 +343,8 @@ __global__ void __launch_bounds__(512, 1) wgrad256_kernel(const WgradParams p)
     const int nwg = p.n_co_tiles * p.n_ci_tiles * p.ntaps;
     int bid;
     long pbeg, pend;
-    wgrad_map(p, nwg, bid, pbeg, pend);
+    bool atomic;
+    wgrad_map(p, nwg, bid, pbeg, pend, atomic);
     if (pbeg >= pend) return;   // empty range of a rounded-up split (the whole workgroup leaves)
     const int co_tile = bid % p.n_co_tiles;
     const int rest = bid / p.n_co_tiles;
@@ -467,7 +471,7 @@ __global__ void __launch_bounds__(512, 1) wgrad256_kernel(const WgradParams p)
                 const int co = co0 + wco * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                 if (co >= p.Cout) continue;
                 float *o = p.dw + (long)co * ldw + (long)tap * p.Cin + ci;
-                if (p.atomic) atomicAdd(o, acc[i][j][r]);
+                if (atomic) atomicAdd(o, acc[i][j][r]);
                 else *o = acc[i][j][r];
             }
         }
@@ -773,7 +777,9 @@ YOLO_API int yolo_wgrad(const yolo_wgrad_desc *d, const void *x, const void *dy,
             p.tail_split = p.tail_tiles > 0 ? bt : 1;
             p.per_main = ((d->P + bs - 1) / bs + WG_BP - 1) / WG_BP * WG_BP;
             p.per_tail = ((d->P + p.tail_split - 1) / p.tail_split + WG_BP - 1) / WG_BP * WG_BP;
-            p.atomic = 1;
+            // a segment whose tiles are reduced by ONE workgroup stores; only split tiles need atomics (dw arrives zero-filled
+            // or holds the value to add to: accumulate forces atomics everywhere)
+            p.atomic = d->accumulate ? 3 : ((bs > 1 ? 1 : 0) | (p.tail_split > 1 ? 2 : 0));
             const long nblk = (long)p.main_tiles * bs + (long)p.tail_tiles * p.tail_split;
             grid = dim3((unsigned)((nblk + WG_SLOTS - 1) / WG_SLOTS * WG_SLOTS));   // whole groups of 512 ids for the XCD map
         }
