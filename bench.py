@@ -155,6 +155,8 @@ def main():
                 "launches_per_step": n_launch, "avg_launch_ms": round(ig_ms / n_launch, 4),
                 "flops_per_launch": ig_fl / n_launch, "flops_per_step": ig_fl, "kernel_ms_per_step": round(ig_ms, 3)}
         if a.layers:
+            for key, plan_ in engine._TUNED.items():
+                print(f"tuned {key} -> {plan_}", file=sys.stderr)
             for k, kern, fl, ms in layer_rows:
                 print(f"{k:14s} {kern:14s} {ms:8.3f} ms {fl / max(ms, 1e-9) / 1e9:9.1f} TFLOP/s", file=sys.stderr)
 

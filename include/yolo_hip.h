@@ -137,6 +137,10 @@ typedef struct yolo_igemm_desc {
     int32_t tile_hint;      /* 0 = let the library pick the tile configuration; 1: 128x128, 2: 256x128
                                (8 waves, 3 stages), 3: 128x64, 4: 64x128, 5/6: 1/2 on the 16x16x32
                                MFMA shape  (tuning / tests)                                        */
+    int64_t px_begin, px_end; /* compute only output pixels [px_begin, px_end) of the flattened (n, oy, ox) index
+                               (0, 0 = all).  Lets a caller run the bulk of a layer with a large tile in whole
+                               rounds of the 256 CUs and the remainder with a small tile in one short round,
+                               instead of a last round that keeps a few CUs busy for a full large-tile time */
 } yolo_igemm_desc;
 
 #define YOLO_EPI_NONE 0        /* out = acc                                                        */
@@ -151,6 +155,12 @@ typedef struct yolo_igemm_desc {
 
 int yolo_igemm(const yolo_igemm_desc *d, const void *in_bf16, const void *w_bf16 /*[Cout][KH*KW*tap_len]*/,
                const float *bias, const void *aux_bf16, void *out, yolo_stream_t stream);
+/* Finishing pass of a split-K convolution.  Few-pixel, deep-K layers (the 7x7x1024 ones: 3136 pixels at batch 64,
+ * K = 9216) have too few output tiles to fill 256 CUs; the caller runs yolo_igemm with split_k > 1, out_fp32 = 1,
+ * YOLO_EPI_NONE into a zero-filled dense fp32 [N*Ho*Wo][Cout] buffer and then this pass, with the layer's REAL
+ * descriptor (epilogue, out_* / aux_* strides), applies bias / LeakyReLU / LeakyReLU'(aux) and writes bf16. */
+int yolo_igemm_finish(const yolo_igemm_desc *d, const float *acc, const float *bias, const void *aux_bf16,
+                      void *out_bf16, yolo_stream_t stream);
 
 /* Weight-gradient of a conv / Linear, "flat" pixel indexing:
  *     dw[co][tap][ci] (+)= sum_{p < P} dy[p*dy_px_stride + co] * x[p*x_px_stride + tapoff(tap) + ci]

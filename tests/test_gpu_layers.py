@@ -310,6 +310,46 @@ def test_every_tile_configuration(hint):
         _close(a, b, 12.0, f"hint {hint} grad {i}", frac=0.01)
 
 
+def test_pixel_range_launches_tile_the_output_exactly():
+    """yolo_igemm_desc.px_begin/px_end: [0, cut) + [cut, M) with ONE configuration is bit-identical to the single launch
+    (cuts on and off tile boundaries); a different small-tile configuration for the tail stays within tolerance --
+    the launch plans the autotuner composes (engine._run_plan_igemm)."""
+    import ctypes
+    from yolo import engine
+    from yolo._hip import lib, check, ptr, stream
+    torch.manual_seed(6)
+    conv = nn.Conv2d(64, 256, 3, 1, 1).cuda()
+    plan = engine.Plan.from_modules([conv, nn.LeakyReLU(0.1)], 64, False)
+    x = torch.randn(5, 64, 20, 24, device="cuda")
+    with torch.no_grad():
+        engine.run_plan(plan, x, False)             # packs the weights, builds the workspace
+    key, ws = plan._workspace(5, x.shape, x.device, False)
+    a_in, a_out = ws["in"], ws["acts"][0]
+    check(lib().yolo_nchw_f32_to_nhwc_bf16(ptr(x), 5, 64, 20, 24, a_in.p, 64, 1, 1, stream()))
+    L = plan.layers[0]
+    wf, _ = plan._pack(0, False)
+    d = plan._conv_desc(L, a_in, a_out)
+    M = 5 * 20 * 24
+
+    def run(pl):
+        a_out.t.zero_()
+        engine._run_plan_igemm(lib(), d, pl, a_in.p, ptr(wf), ptr(L.bias.detach()), None, a_out.p, stream(), "test")
+        return a_out.interior().clone()
+
+    for hint in (5, 11, 12):
+        ref = run((hint, 1))
+        for cut in (256, 1024, 1000, M - 1):
+            assert torch.equal(run((hint, 1, cut, hint)), ref), (hint, cut)
+        mixed = run((hint, 1, 1280, 3))
+        _close(mixed.permute(0, 3, 1, 2), ref.permute(0, 3, 1, 2).float(), 2.0, f"hint {hint} + tail 3")
+        assert torch.equal(mixed.view(-1, 256)[:1280], ref.view(-1, 256)[:1280])
+        sk = run(("splitk", hint if hint != 12 else 3, 3))     # split-K + finishing pass: fp32 atomics, so not bit-identical
+        _close(sk.permute(0, 3, 1, 2), ref.permute(0, 3, 1, 2).float(), 2.0, f"split-K vs hint {hint}")
+    d.px_begin, d.px_end = 10, 5
+    assert lib().yolo_igemm(ctypes.byref(d), a_in.p, ptr(wf), ptr(L.bias.detach()), None, a_out.p, stream()) != 0
+    plan._release(key, ws)
+
+
 def test_fused_pool_epilogue_equals_separate_pool():
     """inference path: conv+LeakyReLU+MaxPool as one launch must equal conv, then pool (bit for bit:
     max and the bf16 rounding commute because rounding is monotone)."""

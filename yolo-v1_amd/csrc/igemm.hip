@@ -59,6 +59,7 @@ struct IgemmParams {
     int nk;                 // K iterations in total
     int nk_per_split;
     int n_co_tiles, n_px_tiles;
+    long px_begin;          // first output pixel of this launch (pixel-range launches: see yolo_igemm_desc.px_begin)
     int px_fastest;         // tile order inside an XCD's contiguous range: 1 = pixel tiles fastest (one weight panel per XCD)
 };
 
@@ -134,7 +135,7 @@ __global__ void __launch_bounds__(WCO * WPX * 64, 2) igemm_kernel(const IgemmPar
     const int co_tile = p.px_fastest ? bid / p.n_px_tiles : bid % p.n_co_tiles;
     const int px_tile = p.px_fastest ? bid % p.n_px_tiles : bid / p.n_co_tiles;
     const int co0 = co_tile * TCO;
-    const long px0 = (long)px_tile * TPX;
+    const long px0 = p.px_begin + (long)px_tile * TPX;
 
     // ---- per-pixel address tables (input row base / output base), one pixel per thread.
     // Normal mode: tile = TPX consecutive pixels of the flattened (n, oy, ox) index.
@@ -538,7 +539,7 @@ static int launch(const IgemmParams &p, int splits, hipStream_t s)
         q.pool_tiles_y = (p.HoWo / p.Wo + TPX / p.pool_tw - 1) / (TPX / p.pool_tw);
         q.n_px_tiles = (int)(p.M / p.HoWo) * q.pool_tiles_x * q.pool_tiles_y;
     } else {
-        q.n_px_tiles = (int)((p.M + TPX - 1) / TPX);
+        q.n_px_tiles = (int)((p.M - p.px_begin + TPX - 1) / TPX);
     }
     q.nk = (int)(p.Ktot / BK);
     // L2 working set: when the weights are much larger than an XCD's 4-MB L2, give each XCD its own weight
@@ -549,6 +550,47 @@ static int launch(const IgemmParams &p, int splits, hipStream_t s)
     const int real_splits = (q.nk + q.nk_per_split - 1) / q.nk_per_split;
     hipLaunchKernelGGL((igemm_kernel<TCO, TPX, BK, WCO, WPX, NST, MF>), dim3(q.n_co_tiles * q.n_px_tiles, real_splits), dim3(Cfg::NTHR), Cfg::LDS_BYTES, s, q);
     return check_launch("yolo_igemm");
+}
+
+// Finishing pass of a split-K conv: acc fp32 [M][Cout] (dense, summed by the split workgroups' atomics) -> the layer's
+// real output with the epilogue the un-split launch would have applied (bias / LeakyReLU / times LeakyReLU'(aux)),
+// bf16 into the zero-haloed NHWC buffer.  One thread = one pixel x 8 channels.
+__global__ void __launch_bounds__(256) igemm_finish_kernel(const float *__restrict__ acc, const float *__restrict__ bias, const bf16_t *__restrict__ aux,
+                                                           bf16_t *__restrict__ out, long M, int HoWo, int Wo, int Cout, int epilogue, float slope,
+                                                           long out_img, int out_row, int out_px, int out_off, long aux_img, int aux_row, int aux_px, int aux_off)
+{
+    const int C8 = Cout >> 3;
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= M * C8) return;
+    const int c = (int)(idx % C8) * 8;
+    const long m = idx / C8;
+    const int n = (int)(m / HoWo);
+    const int rem = (int)(m - (long)n * HoWo);
+    const int oy = rem / Wo, ox = rem - oy * Wo;
+    const float4 a = *reinterpret_cast<const float4 *>(acc + m * Cout + c), b = *reinterpret_cast<const float4 *>(acc + m * Cout + c + 4);
+    float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    if (epilogue == YOLO_EPI_BIAS || epilogue == YOLO_EPI_BIAS_LRELU) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] += bias[c + k];
+    }
+    if (epilogue == YOLO_EPI_BIAS_LRELU) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = v[k] > 0.0f ? v[k] : v[k] * slope;
+    } else if (epilogue == YOLO_EPI_MUL_DLRELU) {
+        const uint4 y = *reinterpret_cast<const uint4 *>(aux + (long)n * aux_img + (long)oy * aux_row + (long)ox * aux_px + aux_off + c);
+        const unsigned yy[4] = {y.x, y.y, y.z, y.w};
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const float t = __uint_as_float((k & 1) ? (yy[k >> 1] & 0xffff0000u) : (yy[k >> 1] << 16));
+            v[k] = t > 0.0f ? v[k] : v[k] * slope;
+        }
+    }
+    uint4 o;
+    o.x = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
+    o.y = (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
+    o.z = (unsigned)f32_to_bf16(v[4]) | ((unsigned)f32_to_bf16(v[5]) << 16);
+    o.w = (unsigned)f32_to_bf16(v[6]) | ((unsigned)f32_to_bf16(v[7]) << 16);
+    *reinterpret_cast<uint4 *>(out + (long)n * out_img + (long)oy * out_row + (long)ox * out_px + out_off + c) = o;
 }
 
 }  // namespace yolo
@@ -573,6 +615,11 @@ YOLO_API int yolo_igemm(const yolo_igemm_desc *d, const void *in, const void *w,
     IgemmParams p{};
     p.in = (const bf16_t *)in; p.w = (const bf16_t *)w; p.bias = bias; p.aux = (const bf16_t *)aux; p.out = out;
     p.M = (long)d->N * d->Ho * d->Wo; p.HoWo = d->Ho * d->Wo; p.Wo = d->Wo;
+    if (d->px_begin < 0 || d->px_end < 0 || d->px_begin > p.M || d->px_end > p.M || (d->px_end && d->px_end <= d->px_begin))
+        return fail(YOLO_E_ARG, "yolo_igemm: bad pixel range [%ld, %ld) of %ld", (long)d->px_begin, (long)d->px_end, (long)p.M);
+    if ((d->px_begin || d->px_end) && d->pool2) return fail(YOLO_E_UNSUPPORTED, "yolo_igemm: pixel ranges are not available with pool2");
+    p.px_begin = d->px_begin;
+    if (d->px_end) p.M = d->px_end;   // the kernels bound pixels by p.M
     p.in_img_stride = d->in_img_stride; p.in_row_stride = d->in_row_stride; p.in_px_stride = d->in_px_stride; p.in_off = d->in_off; p.stride = d->stride;
     p.KH = d->KH; p.KW = d->KW; p.tap_len = d->tap_len; p.Cout = d->Cout;
     p.Ktot = (long)d->KH * d->KW * d->tap_len;
@@ -583,7 +630,8 @@ YOLO_API int yolo_igemm(const yolo_igemm_desc *d, const void *in, const void *w,
 
     const bool bk64 = (d->tap_len % 64) == 0;
     const bool small_co = d->Cout <= 64 || (d->Cout % 128 != 0 && d->Cout % 64 == 0 && d->Cout < 512);
-    const long tiles128 = ((p.M + 127) / 128) * ((d->Cout + 127) / 128);
+    const long npx = p.M - p.px_begin;   // pixels of this launch
+    const long tiles128 = ((npx + 127) / 128) * ((d->Cout + 127) / 128);
     const int force = d->tile_hint;   // 0 = heuristic; tests / tuning may force a configuration
     p.w_blocked = d->w_blocked;
     p.px_fastest = d->tile_order == 1 ? 0 : (d->tile_order == 2 ? 1 : -1);
@@ -593,7 +641,7 @@ YOLO_API int yolo_igemm(const yolo_igemm_desc *d, const void *in, const void *w,
         return fail(YOLO_E_UNSUPPORTED, "yolo_igemm: pool2 needs even Ho/Wo, bf16 output, a bias epilogue and no split-K");
     if (d->w_blocked) {
         if (!bk64) return fail(YOLO_E_UNSUPPORTED, "yolo_igemm: blocked weights need tap_len %% 64 == 0");
-        return p.M <= 64 ? launch<128, 64, 64, 2, 2, 2, MFMA_16x16x32>(p, splits, s) : launch<128, 128, 64, 2, 2, 2, MFMA_16x16x32>(p, splits, s);
+        return npx <= 64 ? launch<128, 64, 64, 2, 2, 2, MFMA_16x16x32>(p, splits, s) : launch<128, 128, 64, 2, 2, 2, MFMA_16x16x32>(p, splits, s);
     }
     if (force == 12) return launch<256, 256, 32, 2, 4, 4, MFMA_16x16x32_STAGGER>(p, splits, s);
     if (force == 13) return launch<256, 128, 32, 4, 2, 4, MFMA_16x16x32_STAGGER>(p, splits, s);
@@ -616,11 +664,28 @@ YOLO_API int yolo_igemm(const yolo_igemm_desc *d, const void *in, const void *w,
     if (force == 5) return launch<128, 128, 64, 2, 2, 2, MFMA_16x16x32>(p, splits, s);
     if (force == 6) return launch<256, 128, 64, 4, 2, 3, MFMA_16x16x32>(p, splits, s);
     if (force == 11) return launch<256, 128, 64, 4, 2, 3, MFMA_16x16x32_STAGGER>(p, splits, s);
-    if (p.M <= 64) return small_co ? launch<64, 64, 64, 2, 2, 2, MFMA_16x16x32>(p, splits, s) : launch<128, 64, 64, 2, 2, 2, MFMA_16x16x32>(p, splits, s);
+    if (npx <= 64) return small_co ? launch<64, 64, 64, 2, 2, 2, MFMA_16x16x32>(p, splits, s) : launch<128, 64, 64, 2, 2, 2, MFMA_16x16x32>(p, splits, s);
     if (small_co) return launch<64, 128, 64, 2, 2, 2, MFMA_16x16x32>(p, splits, s);
     // (the 256x128 8-wave 3-stage configuration is built and tested but measured slower than 128x128
     //  on every layer of this network -- it is reachable through tile_hint only)
     // few tiles (7x7 layers): halve the pixel tile to double the number of workgroups
     if (tiles128 * splits < 320 && d->Cout >= 128) return launch<128, 64, 64, 2, 2, 2, MFMA_16x16x32>(p, splits, s);
     return launch<128, 128, 64, 2, 2, 2, MFMA_16x16x32>(p, splits, s);   // measured 3-8 % faster than 32x32x16 on the 3x3 layers
+}
+
+YOLO_API int yolo_igemm_finish(const yolo_igemm_desc *d, const float *acc, const float *bias, const void *aux, void *out, yolo_stream_t stream)
+{
+    if (!d || !acc || !out) return fail(YOLO_E_ARG, "yolo_igemm_finish: null pointer");
+    if (d->epilogue != YOLO_EPI_NONE && d->epilogue != YOLO_EPI_BIAS && d->epilogue != YOLO_EPI_BIAS_LRELU && d->epilogue != YOLO_EPI_MUL_DLRELU)
+        return fail(YOLO_E_UNSUPPORTED, "yolo_igemm_finish: epilogue %d", d->epilogue);
+    if ((d->epilogue == YOLO_EPI_BIAS || d->epilogue == YOLO_EPI_BIAS_LRELU) && !bias) return fail(YOLO_E_ARG, "yolo_igemm_finish: epilogue needs bias");
+    if (d->epilogue == YOLO_EPI_MUL_DLRELU && !aux) return fail(YOLO_E_ARG, "yolo_igemm_finish: epilogue needs aux");
+    if (d->out_fp32 || d->pool2 || (d->Cout & 7) || (d->out_off & 7) || (d->out_px_stride & 7) || (d->out_row_stride & 7) || (d->out_img_stride & 7))
+        return fail(YOLO_E_UNSUPPORTED, "yolo_igemm_finish: bf16 output with Cout and strides in multiples of 8, no pool2");
+    const long M = (long)d->N * d->Ho * d->Wo;
+    const long total = M * (d->Cout / 8);
+    hipLaunchKernelGGL(igemm_finish_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, STRM(stream), acc, bias, (const bf16_t *)aux, (bf16_t *)out, M,
+                       d->Ho * d->Wo, d->Wo, d->Cout, d->epilogue, d->slope, (long)d->out_img_stride, d->out_row_stride, d->out_px_stride, d->out_off,
+                       (long)d->aux_img_stride, d->aux_row_stride, d->aux_px_stride, d->aux_off);
+    return check_launch("yolo_igemm_finish");
 }

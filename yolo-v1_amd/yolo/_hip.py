@@ -37,6 +37,7 @@ class IgemmDesc(ctypes.Structure):
         ("w_blocked", ctypes.c_int32),
         ("tile_order", ctypes.c_int32),
         ("tile_hint", ctypes.c_int32),
+        ("px_begin", ctypes.c_int64), ("px_end", ctypes.c_int64),
     ]
 
 
@@ -93,6 +94,7 @@ _SIGS = {
     "yolo_loss_fwd_bwd": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p],
     "yolo_loss_iou": [c_void_p, c_void_p, c_long, c_void_p, c_void_p],
     "yolo_igemm": [ctypes.POINTER(IgemmDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
+    "yolo_igemm_finish": [ctypes.POINTER(IgemmDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
     "yolo_wgrad": [ctypes.POINTER(WgradDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
     "yolo_wgrad_stem7": [c_void_p, c_void_p, c_int, c_int, c_int, c_long, c_int, c_long, c_int, c_int, c_void_p, c_void_p, c_void_p, c_long, c_void_p],
     "yolo_maxpool3s2_fwd": [ctypes.POINTER(PoolDesc), c_void_p, c_void_p, c_void_p],

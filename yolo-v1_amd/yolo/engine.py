@@ -77,8 +77,40 @@ def _flush_caches(dev):
     _FLUSH.fill_(1)
 
 
+# tile edge (co, px) of the configurations the tuner may combine
+_TILE = {1: (128, 128), 3: (128, 64), 4: (64, 128), 5: (128, 128), 11: (256, 128), 12: (256, 256), 13: (256, 128)}
+_TAIL_CANDIDATES = (5, 3, 4)
+
+
+def _run_plan_igemm(L_, d: IgemmDesc, plan, inp, w, bias, aux, out, st, what):
+    """plan = (hint, order) | (hint, order, px_cut, tail_hint): the second form runs pixels [0, px_cut) with the large
+    tile `hint` -- whole rounds of the chip -- and the rest with the small tile `tail_hint` in one short round."""
+    if plan[0] == "splitk":
+        # ("splitk", hint, S): few-pixel deep-K layer -- S workgroups per output tile, fp32 atomics into a dense scratch,
+        # then the epilogue as a separate pass (yolo_igemm_finish)
+        M = d.N * d.Ho * d.Wo
+        acc = torch.zeros((M, d.Cout), dtype=torch.float32, device=torch.device("cuda", torch.cuda.current_device()))
+        d2 = IgemmDesc.from_buffer_copy(d)
+        d2.out_fp32, d2.epilogue, d2.split_k, d2.tile_hint, d2.tile_order = 1, EPI_NONE, plan[2], plan[1], 1
+        d2.out_img_stride, d2.out_row_stride, d2.out_px_stride, d2.out_off = d.Ho * d.Wo * d.Cout, d.Wo * d.Cout, d.Cout, 0
+        d2.px_begin, d2.px_end = 0, 0
+        check(L_.yolo_igemm(ctypes.byref(d2), inp, w, None, None, ptr(acc), st), what)
+        check(L_.yolo_igemm_finish(ctypes.byref(d), ptr(acc), bias, aux, out, st), what + " (finish)")
+        return
+    d.tile_hint, d.tile_order = plan[0], plan[1]
+    if len(plan) == 2:
+        d.px_begin, d.px_end = 0, 0
+        check(L_.yolo_igemm(ctypes.byref(d), inp, w, bias, aux, out, st), what)
+        return
+    d.px_begin, d.px_end = 0, plan[2]
+    check(L_.yolo_igemm(ctypes.byref(d), inp, w, bias, aux, out, st), what)
+    d.tile_hint, d.px_begin, d.px_end = plan[3], plan[2], 0
+    check(L_.yolo_igemm(ctypes.byref(d), inp, w, bias, aux, out, st), what)
+    d.px_begin, d.px_end = 0, 0
+
+
 def igemm_call(d: IgemmDesc, inp, w, bias, aux, out, st, what: str):
-    """yolo_igemm with the cached / autotuned (tile configuration, tile order) -- only for plain, idempotent launches."""
+    """yolo_igemm with the cached / autotuned launch plan -- only for plain, idempotent launches."""
     L_ = lib()
     plain = TILE_HINT == 0 and d.split_k <= 1 and not d.w_blocked and d.tap_len % 64 == 0
     if not plain:
@@ -89,32 +121,64 @@ def igemm_call(d: IgemmDesc, inp, w, bias, aux, out, st, what: str):
     best = _TUNED.get(key)
     if best is None and AUTOTUNE and TIMERS is None and d.N * d.Ho * d.Wo >= 2048:
         dev = torch.device("cuda", torch.cuda.current_device())
+
+        def timed(plan):
+            try:
+                _run_plan_igemm(L_, d, plan, inp, w, bias, aux, out, st, what)
+                ts = []
+                for _ in range(3):
+                    _flush_caches(dev)
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    _run_plan_igemm(L_, d, plan, inp, w, bias, aux, out, st, what)
+                    e1.record()
+                    e1.synchronize()
+                    ts.append(e0.elapsed_time(e1))
+                return min(ts)
+            except RuntimeError:
+                return None
+
         cands = [c for c in _TUNE_CANDIDATES if not (d.pool2 and c in (3, 12))]
         orders = (1, 2) if (d.Cout * d.KH * d.KW * d.tap_len * 2 > (4 << 20) and d.Cout >= 1024) else (1,)
         times = {}
         for c in cands:
             for o in orders:
-                d.tile_hint, d.tile_order = c, o
-                try:
-                    check(L_.yolo_igemm(ctypes.byref(d), inp, w, bias, aux, out, st), what)
-                    ts = []
-                    for _ in range(3):
-                        _flush_caches(dev)
-                        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                        e0.record()
-                        check(L_.yolo_igemm(ctypes.byref(d), inp, w, bias, aux, out, st), what)
-                        e1.record()
-                        e1.synchronize()
-                        ts.append(e0.elapsed_time(e1))
-                    times[(c, o)] = min(ts)
-                except RuntimeError:
-                    continue
+                t = timed((c, o))
+                if t is not None:
+                    times[(c, o)] = t
+        # tail plans: the two fastest large-tile configurations, cut where their tiles stop filling whole rounds of
+        # 256 (one workgroup per CU) or 512 slots, remainder with a small tile
+        if times and not d.pool2:
+            M = d.N * d.Ho * d.Wo
+            singles = sorted(times, key=times.get)
+            for (c, o) in [pl for pl in singles if _TILE[pl[0]][0] * _TILE[pl[0]][1] >= 128 * 128][:2]:
+                tco, tpx = _TILE[c]
+                n_co = (d.Cout + tco - 1) // tco
+                tiles = n_co * ((M + tpx - 1) // tpx)
+                cuts = set()
+                for slots in (256, 512):
+                    full = tiles // slots * slots
+                    cut = full // n_co * tpx
+                    if 0 < cut < M and tiles - full < 0.9 * slots:
+                        cuts.add(cut)
+                for cut in sorted(cuts):
+                    for tc in _TAIL_CANDIDATES:
+                        t = timed((c, o, cut, tc))
+                        if t is not None:
+                            times[(c, o, cut, tc)] = t
+        # split-K plans for few-pixel, deep-K layers (7x7x1024: 200 output tiles of 128x128 for 256 CUs)
+        if (times and not d.pool2 and not d.out_fp32 and d.N * d.Ho * d.Wo <= 8192 and d.KH * d.KW * d.tap_len >= 2304 and d.Cout % 8 == 0
+                and d.epilogue in (EPI_NONE, EPI_BIAS, EPI_BIAS_LRELU, EPI_MUL_DLRELU)):
+            for c in (5, 3, 11):
+                for S in (2, 3, 4):
+                    t = timed(("splitk", c, S))
+                    if t is not None:
+                        times[("splitk", c, S)] = t
         best = min(times, key=times.get) if times else (0, 0)
         _TUNED[key] = best
     if best is None:
         best = (0, 0)
-    d.tile_hint, d.tile_order = best
-    check(L_.yolo_igemm(ctypes.byref(d), inp, w, bias, aux, out, st), what)
+    _run_plan_igemm(L_, d, best, inp, w, bias, aux, out, st, what)
 
 
 def _tune_key(d: IgemmDesc):
