@@ -8,12 +8,16 @@ import csv, json, sys, collections
 d = sys.argv[1]
 tot = {}
 n = {}
-LAST = int(sys.argv[2]) if len(sys.argv) > 2 else 156   # igemm launches of the timed steps + roofline pass (2 x 3 x 26);
-                                                         # everything earlier is warm-up / tile autotuning
+LAST = int(sys.argv[2]) if len(sys.argv) > 2 else 0     # 0: the launches of the last 6 forward passes (timed steps + roofline pass),
+                                                         # found from bench's own launch count; everything earlier is warm-up / tuning
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
     rows = [(int(r["Dispatch_Id"]), float(r["Counter_Value"])) for r in csv.DictReader(open(f"{d}/pmc_{c}_counter_collection.csv"))
             if "igemm_kernel" in r["Kernel_Name"] and r["Counter_Name"] == c]
     rows.sort()
+    if not LAST:
+        import glob
+        per = json.loads(open(glob.glob(f"{d}/bench_*.json")[0]).read().strip().splitlines()[-1])["roofline"]["launches_per_step"]
+        LAST = 6 * per
     rows = rows[-LAST:]
     tot[c], n[c] = sum(v for _, v in rows), len(rows)
 launches = n["FETCH_SIZE"]

@@ -37,7 +37,14 @@ def _round_up(a: int, b: int) -> int:
 TIMERS: list | None = None
 # tests / tuning: force a tile configuration of yolo_igemm (0 = library heuristic, see yolo_igemm_desc.tile_hint)
 TILE_HINT = 0
+IGEMM_LAUNCHES = 0  # yolo_igemm launches so far (bench.py: launches per step of the dominant kernel)
 FUSE_POOL = True   # inference: fold MaxPool2d(2,2) into the preceding conv's epilogue where the geometry allows
+
+
+def _igemm(L_, d, inp, w, bias, aux, out, st, what):
+    global IGEMM_LAUNCHES
+    IGEMM_LAUNCHES += 1
+    check(L_.yolo_igemm(ctypes.byref(d), inp, w, bias, aux, out, st), what)
 
 
 class _timed:
@@ -94,18 +101,18 @@ def _run_plan_igemm(L_, d: IgemmDesc, plan, inp, w, bias, aux, out, st, what):
         d2.out_fp32, d2.epilogue, d2.split_k, d2.tile_hint, d2.tile_order = 1, EPI_NONE, plan[2], plan[1], 1
         d2.out_img_stride, d2.out_row_stride, d2.out_px_stride, d2.out_off = d.Ho * d.Wo * d.Cout, d.Wo * d.Cout, d.Cout, 0
         d2.px_begin, d2.px_end = 0, 0
-        check(L_.yolo_igemm(ctypes.byref(d2), inp, w, None, None, ptr(acc), st), what)
+        _igemm(L_, d2, inp, w, None, None, ptr(acc), st, what)
         check(L_.yolo_igemm_finish(ctypes.byref(d), ptr(acc), bias, aux, out, st), what + " (finish)")
         return
     d.tile_hint, d.tile_order = plan[0], plan[1]
     if len(plan) == 2:
         d.px_begin, d.px_end = 0, 0
-        check(L_.yolo_igemm(ctypes.byref(d), inp, w, bias, aux, out, st), what)
+        _igemm(L_, d, inp, w, bias, aux, out, st, what)
         return
     d.px_begin, d.px_end = 0, plan[2]
-    check(L_.yolo_igemm(ctypes.byref(d), inp, w, bias, aux, out, st), what)
+    _igemm(L_, d, inp, w, bias, aux, out, st, what)
     d.tile_hint, d.px_begin, d.px_end = plan[3], plan[2], 0
-    check(L_.yolo_igemm(ctypes.byref(d), inp, w, bias, aux, out, st), what)
+    _igemm(L_, d, inp, w, bias, aux, out, st, what)
     d.px_begin, d.px_end = 0, 0
 
 
@@ -115,7 +122,7 @@ def igemm_call(d: IgemmDesc, inp, w, bias, aux, out, st, what: str):
     plain = TILE_HINT == 0 and d.split_k <= 1 and not d.w_blocked and d.tap_len % 64 == 0
     if not plain:
         d.tile_hint = TILE_HINT
-        check(L_.yolo_igemm(ctypes.byref(d), inp, w, bias, aux, out, st), what)
+        _igemm(L_, d, inp, w, bias, aux, out, st, what)
         return
     key = _tune_key(d)
     best = _TUNED.get(key)
@@ -594,7 +601,7 @@ class Plan:
                     acc = torch.zeros((N, L.Cout), dtype=torch.float32, device=dev)
                     d.epilogue, d.split_k = EPI_NONE, splits
                     with _timed(f"fc{li}", "igemm", 2.0 * N * L.Cout * L.Cin):
-                        check(L_.yolo_igemm(ctypes.byref(d), ptr(xin), ptr(wf), None, None, ptr(acc), st), f"igemm fc{li}")
+                        _igemm(L_, d, ptr(xin), ptr(wf), None, None, ptr(acc), st, f"igemm fc{li}")
                     yb = torch.empty((N, L.Cout), dtype=torch.bfloat16, device=dev) if not last else None
                     yf = torch.empty((N, L.Cout), dtype=torch.float32, device=dev) if last else None
                     check(L_.yolo_bias_lrelu_rows(ptr(acc), ptr(b), N, L.Cout, self.SLOPE if L.lrelu else 1.0, ptr(yb), ptr(yf), st), "bias_lrelu_rows")
@@ -602,7 +609,7 @@ class Plan:
                     yf = torch.empty((N, L.Cout), dtype=torch.float32, device=dev)
                     d.epilogue, d.split_k = (EPI_BIAS_LRELU if L.lrelu else EPI_BIAS), 1
                     with _timed(f"fc{li}", "igemm", 2.0 * N * L.Cout * L.Cin):
-                        check(L_.yolo_igemm(ctypes.byref(d), ptr(xin), ptr(wf), ptr(b), None, ptr(yf), st), f"igemm fc{li}")
+                        _igemm(L_, d, ptr(xin), ptr(wf), ptr(b), None, ptr(yf), st, f"igemm fc{li}")
                     yb = None
                     if not last:
                         yb = torch.empty((N, L.Cout), dtype=torch.bfloat16, device=dev)
@@ -785,7 +792,7 @@ class Plan:
                     d.epilogue, d.slope, d.out_fp32, d.split_k = EPI_NONE, self.SLOPE, 1, 1
                     gprev = torch.empty((N, L.Cin), dtype=torch.float32, device=dev)
                     with _timed(f"fc{li}.dgrad", "igemm", 2.0 * N * L.Cout * L.Cin):
-                        check(L_.yolo_igemm(ctypes.byref(d), ptr(gb), ptr(wt), None, None, ptr(gprev), st), f"dgrad fc{li}")
+                        _igemm(L_, d, ptr(gb), ptr(wt), None, None, ptr(gprev), st, f"dgrad fc{li}")
                     g_flat = gprev
                 li -= 1
             elif L.kind == "flatten":
@@ -931,7 +938,7 @@ class Plan:
         d.stride, d.KH, d.KW, d.tap_len, d.Cout = 1, L.K, L.K, L.Cout, L.Cin
         d.out_img_stride, d.out_row_stride, d.out_px_stride, d.out_off = gi.img_stride, gi.row_stride, gi.px_stride, gi.interior_off()
         d.epilogue, d.slope, d.out_fp32, d.split_k = EPI_NONE, self.SLOPE, 0, 1
-        check(lib().yolo_igemm(ctypes.byref(d), g.p, ptr(wdg), None, None, gi.p, st), "dgrad input")
+        _igemm(lib(), d, g.p, ptr(wdg), None, None, gi.p, st, "dgrad input")
         gx = torch.empty((N, L.Cin, L.Hin, L.Win), dtype=torch.float32, device=dev)
         check(lib().yolo_nhwc_bf16_to_nchw_f32(gi.p, N, L.Cin, L.Hin, L.Win, 1, ptr(gx), st), "gx nhwc->nchw")
         return gx
@@ -1045,7 +1052,7 @@ class ResNetPlan:
         else:
             d.epilogue = EPI_BIAS_LRELU if relu else EPI_BIAS
         with _timed(str(tag), "igemm", 2.0 * N * Ho * Wo * conv.out_channels * conv.in_channels * k * k):
-            check(lib().yolo_igemm(ctypes.byref(d), a_in.p, ptr(wf), ptr(b), aux, a_out.p, st), f"igemm {tag}")
+            _igemm(lib(), d, a_in.p, ptr(wf), ptr(b), aux, a_out.p, st, f"igemm {tag}")
         return a_out
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
@@ -1071,7 +1078,7 @@ class ResNetPlan:
         d.out_img_stride, d.out_row_stride, d.out_px_stride, d.out_off = s1.img_stride, s1.row_stride, s1.px_stride, s1.interior_off()
         d.epilogue, d.slope = EPI_BIAS_LRELU, 0.0
         with _timed("stem", "igemm", 2.0 * N * Ho * Wo * 64 * 147):
-            check(lib().yolo_igemm(ctypes.byref(d), a.p, ptr(wf), ptr(b), None, s1.p, st), "igemm stem")
+            _igemm(lib(), d, a.p, ptr(wf), ptr(b), None, s1.p, st, "igemm stem")
         Hq, Wq = (Ho - 1) // 2 + 1, (Wo - 1) // 2 + 1
         cur = self._act("pool", N, Hq, Wq, 64, 1, dev)
         pd = PoolDesc(N, Ho, Wo, 64, 1, 1)
