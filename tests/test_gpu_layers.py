@@ -237,6 +237,29 @@ def test_multi_layer_pack_and_unpack_are_exact():
     assert lib().yolo_pack_conv_weights_multi((ConvPackItem * 1)(bad), 1, stream()) != 0
 
 
+def test_stem_forward_kernel_matches_generic_igemm():
+    """yolo_conv_stem7_fwd (patch staged once, weights in registers) vs the generic row-segment implicit GEMM: same
+    bf16-rounded operands, fp32 accumulation in a different order -> equal to a bf16 ulp; with and without the fused pool."""
+    from yolo import engine
+    torch.manual_seed(12)
+    mods = nn.Sequential(nn.Conv2d(3, 64, 7, 2, 3), nn.LeakyReLU(0.1), nn.MaxPool2d(2, 2)).cuda().eval()
+    x = torch.randn(3, 3, 96, 128, device="cuda")          # output 48 x 64 -> 6 x 4 tiles per image
+    outs = {}
+    for stem in (True, False):
+        for fuse in (True, False):
+            engine.STEM_KERNEL, engine.FUSE_POOL = stem, fuse
+            try:
+                plan = engine.Plan.from_modules(list(mods), 3, True)
+                with torch.no_grad():
+                    outs[(stem, fuse)] = engine.run_plan(plan, x, False)
+            finally:
+                engine.STEM_KERNEL, engine.FUSE_POOL = True, True
+    assert torch.equal(outs[(True, True)], outs[(True, False)]), "fused pool must equal conv-then-pool bit for bit"
+    _close(outs[(True, True)], outs[(False, True)], 1.0, "stem kernel vs igemm")
+    ref = mods.cpu()(_bf(x.cpu()))
+    _close(outs[(True, True)], ref, 2.0, "stem kernel vs torch")
+
+
 def test_stem_wgrad_direct_kernel():
     """yolo_wgrad_stem7 (7x7/s2 stem, unfolding in the LDS read addresses) vs fp32 torch on bf16-rounded operands:
     several tiles per workgroup, N > 1, and bit-reproducible (fixed-order partial sums)."""

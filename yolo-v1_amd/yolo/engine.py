@@ -38,6 +38,7 @@ TIMERS: list | None = None
 # tests / tuning: force a tile configuration of yolo_igemm (0 = library heuristic, see yolo_igemm_desc.tile_hint)
 TILE_HINT = 0
 IGEMM_LAUNCHES = 0  # yolo_igemm launches so far (bench.py: launches per step of the dominant kernel)
+STEM_KERNEL = True  # 7x7/s2 stem through yolo_conv_stem7_fwd (False: the generic row-segment implicit GEMM; tests compare)
 FUSE_POOL = True   # inference: fold MaxPool2d(2,2) into the preceding conv's epilogue where the geometry allows
 
 
@@ -177,10 +178,11 @@ def igemm_call(d: IgemmDesc, inp, w, bias, aux, out, st, what: str):
         if (times and not d.pool2 and not d.out_fp32 and d.N * d.Ho * d.Wo <= 8192 and d.KH * d.KW * d.tap_len >= 2304 and d.Cout % 8 == 0
                 and d.epilogue in (EPI_NONE, EPI_BIAS, EPI_BIAS_LRELU, EPI_MUL_DLRELU)):
             for c in (5, 3, 11):
-                for S in (2, 3, 4):
-                    t = timed(("splitk", c, S))
-                    if t is not None:
-                        times[("splitk", c, S)] = t
+                # two K-halves only: 0 + a + b is the same fp32 number in either arrival order, so the forward stays
+                # bit-reproducible run to run (three or more partial sums would not be)
+                t = timed(("splitk", c, 2))
+                if t is not None:
+                    times[("splitk", c, 2)] = t
         best = min(times, key=times.get) if times else (0, 0)
         _TUNED[key] = best
     if best is None:
@@ -564,6 +566,15 @@ class Plan:
                 d = self._conv_desc(L, cur, nxt)
                 d.pool2 = 1 if fuse else 0
                 b = L.bias.detach()
+                if L.first and STEM_KERNEL and L.Cout == 64 and L.Hout % 8 == 0 and L.Wout % 16 == 0 and nxt.C == 64 and b.dtype == torch.float32:
+                    # dedicated stem kernel: input patch staged once per 8x16 tile, weights in registers
+                    with _timed(f"conv{li}" + ("+pool" if fuse else ""), "stem", 2.0 * N * L.Hout * L.Wout * L.Cout * L.Cin * L.K * L.K):
+                        check(L_.yolo_conv_stem7_fwd(cur.p, ptr(wf), ptr(b), N, L.Hout, L.Wout, cur.img_stride, cur.row_stride,
+                                                     self.SLOPE if L.lrelu else 1.0, 1 if fuse else 0, nxt.p, nxt.img_stride, nxt.row_stride,
+                                                     nxt.interior_off(), st), "conv_stem7_fwd")
+                    cur = nxt
+                    skip_pool = fuse
+                    continue
                 with _timed(f"conv{li}" + ("+pool" if fuse else ""), "igemm", 2.0 * N * L.Hout * L.Wout * L.Cout * L.Cin * L.K * L.K):
                     igemm_call(d, cur.p, ptr(wf), ptr(b), None, nxt.p, st, f"igemm conv{li}")
                 cur = nxt
@@ -1077,8 +1088,13 @@ class ResNetPlan:
         d.stride, d.KH, d.KW, d.tap_len, d.Cout = 2, 7, 1, 32, 64
         d.out_img_stride, d.out_row_stride, d.out_px_stride, d.out_off = s1.img_stride, s1.row_stride, s1.px_stride, s1.interior_off()
         d.epilogue, d.slope = EPI_BIAS_LRELU, 0.0
-        with _timed("stem", "igemm", 2.0 * N * Ho * Wo * 64 * 147):
-            _igemm(lib(), d, a.p, ptr(wf), ptr(b), None, s1.p, st, "igemm stem")
+        if STEM_KERNEL and Ho % 8 == 0 and Wo % 16 == 0:
+            with _timed("stem", "stem", 2.0 * N * Ho * Wo * 64 * 147):
+                check(lib().yolo_conv_stem7_fwd(a.p, ptr(wf), ptr(b), N, Ho, Wo, a.img_stride, a.row_stride, 0.0, 0, s1.p, s1.img_stride, s1.row_stride,
+                                                s1.interior_off(), st), "conv_stem7_fwd")
+        else:
+            with _timed("stem", "igemm", 2.0 * N * Ho * Wo * 64 * 147):
+                _igemm(lib(), d, a.p, ptr(wf), ptr(b), None, s1.p, st, "igemm stem")
         Hq, Wq = (Ho - 1) // 2 + 1, (Wo - 1) // 2 + 1
         cur = self._act("pool", N, Hq, Wq, 64, 1, dev)
         pd = PoolDesc(N, Ho, Wo, 64, 1, 1)
