@@ -224,6 +224,28 @@ def main():
         dtp = (time.perf_counter() - t0) / 200
         nms = {"value": round(64 * 98 / dtp, 1), "unit": "raw boxes/s", "us_per_batch64": round(dtp * 1e6, 1), "config": "64x(7,7,30)~U(0,1), conf 0.3, nms 0.4, metrics variant"}
 
+    # ---------------------------------------------------------------- preprocessing on the device
+    pre = None
+    if not a.no_nms and rank == 0:
+        from yolo.preprocess import preprocess_u8
+        u8 = torch.from_numpy(np.random.Generator(np.random.PCG64([0, 5])).integers(0, 256, size=(64, 375, 500, 3), dtype=np.uint8)).to(dev)
+
+        def timeit(fn, reps):
+            for _ in range(3):
+                fn()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                fn()
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t0) / reps
+
+        dt_p = timeit(lambda: preprocess_u8(u8, (448, 448), nchw=False, nhwc4_halo=3), 50)
+        dt_e = timeit(lambda: model.forward_uint8(u8), 10)
+        pre = {"value": round(64 / dt_p, 1), "unit": "images/s", "us_per_batch64": round(dt_p * 1e6, 1),
+               "config": "64 decoded uint8 RGB images 375x500 resident in HBM -> Resize(448,448) (Pillow BILINEAR, bit-exact) + ToTensor + Normalize -> NHWC4 bf16",
+               "forward_from_uint8": {"value": round(64 / dt_e, 1), "unit": "images/s", "ms_per_batch64": round(dt_e * 1e3, 3)}}
+
     # ---------------------------------------------------------------- ResNet50 variant (configs[4])
     resnet = None
     if a.resnet and rank == 0:
@@ -267,6 +289,18 @@ def main():
             dtc = time.perf_counter() - t0
         cpu = {"value": round(n_img / dtc, 2), "unit": "images/s", "cores": cores, "kind": "port",
                "sample": f"forward of oracle/torch_ref.RefYOLOv1 (stock torch.nn fp32, the reference's layer table) on batches of 8, {n_img} images in {dtc:.1f} s"}
+        if pre is not None:
+            from PIL import Image
+            from oracle import preprocess_ref as PR
+            hu8 = u8[:8].cpu().numpy()
+            t0 = time.perf_counter()
+            n_pp = 0
+            while time.perf_counter() - t0 < 3.0:
+                for i in range(8):
+                    PR.to_tensor_normalize(np.asarray(Image.fromarray(hu8[i]).resize((448, 448), Image.BILINEAR)))
+                n_pp += 8
+            pre["cpu_baseline"] = {"value": round(n_pp / (time.perf_counter() - t0), 1), "unit": "images/s", "cores": 1, "kind": "port",
+                                   "sample": f"PIL.Image.resize(BILINEAR) + NumPy ToTensor/Normalize (the reference's host transform), {n_pp} images"}
         if nms is not None:
             pn = p01.cpu().numpy()
             t0 = time.perf_counter()
@@ -286,7 +320,7 @@ def main():
             "config": {"workload": "BASELINE.json configs[1]: batch=64/GPU 448x448 forward-only, YOLOv1Backbone + FC head, 1xMI355X per rank",
                        "global_batch": world * B, "per_gpu_batch": B, "weights": "random init (torch default, seed 0)",
                        "flops_per_image": 40.57e9, "parallelism": f"dp{world}" if world > 1 else "single"},
-            "roofline": roof, "cpu_baseline": cpu, "train": train, "nms": nms, "resnet50_variant": resnet,
+            "roofline": roof, "cpu_baseline": cpu, "train": train, "nms": nms, "preprocess": pre, "resnet50_variant": resnet,
         }
         print(json.dumps(out))
     if use_dist:

@@ -336,6 +336,22 @@ int yolo_adam_step_multi(const yolo_adam_tensor *t, int count, float lr, float b
 /* g *= min(1, max_norm / (sqrt(*norm_sq) + 1e-6))  (stand-alone clip_grad_norm_ for other optimizers). */
 int yolo_clip_scale_f32(float *g, long n, const double *norm_sq, float max_norm, yolo_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Image preprocessing.  Replaces YOLOInference.transform / the eval transform of the reference
+ * (src/yolo/inference.py:58-66, src/yolo/dataset.py:224-233): Resize((Ho,Wo)) = PIL.Image.resize(BILINEAR) ->
+ * ToTensor (/255) -> Normalize(mean, std), from decoded uint8 RGB [N][Hs][Ws][3] in device memory.
+ * Resize is Pillow's two-pass 8-bit resampling, bit-exact: hbounds/vbounds = int32 [out][2] (first input index,
+ * count), hcoef/vcoef = int32 [out][k] 22-bit fixed-point weights, computed by the host exactly as Pillow's
+ * precompute_coeffs + normalize_coeffs_8bpc do (yolo/preprocess.py); tables may be NULL for an axis whose size does
+ * not change; tmp = uint8 [N][Hs][Wo][3] scratch for the horizontal pass.  mean3 / std3 are HOST pointers.
+ * Outputs (either may be NULL): out_nhwc4 = zero-haloed NHWC4 bf16 [N][Ho+2h][Wo+2h][4] (interior written, channel 3 = 0:
+ * the stem's input, = yolo_nchw_f32_to_nhwc_bf16 of the fp32 result), out_nchw = fp32 [N][3][Ho][Wo] (what the
+ * reference's transform returns). */
+int yolo_preprocess_u8(const unsigned char *src_u8, int N, int Hs, int Ws, int Ho, int Wo, const int32_t *hbounds,
+                       const int32_t *hcoef, int hk, const int32_t *vbounds, const int32_t *vcoef, int vk,
+                       unsigned char *tmp_u8, const float *mean3, const float *std3, void *out_nhwc4_bf16, int halo,
+                       float *out_nchw, yolo_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -116,6 +116,8 @@ _SIGS = {
     "yolo_fc_dgrad_to_nhwc": [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_float, c_void_p, c_void_p],
     "yolo_cast_f32_to_bf16": [c_void_p, c_long, c_void_p, c_void_p],
     "yolo_cast_bf16_to_f32": [c_void_p, c_long, c_void_p, c_void_p],
+    "yolo_preprocess_u8": [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p,
+                           ctypes.POINTER(c_float), ctypes.POINTER(c_float), c_void_p, c_int, c_void_p, c_void_p],
     "yolo_sumsq_f32": [c_void_p, c_long, c_void_p, c_void_p],
     "yolo_adam_step": [c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_float, c_float, c_float, c_float, c_float, c_long, c_void_p, c_float, c_void_p, c_void_p],
     "yolo_clip_scale_f32": [c_void_p, c_long, c_void_p, c_float, c_void_p],

@@ -531,23 +531,33 @@ class Plan:
         return d
 
     # ------------------------------------------------------------------ forward
-    def forward(self, x: torch.Tensor, train: bool, drop_training: bool):
-        """x: NCHW fp32 device tensor.  Returns (out, saved) -- out is (N, O) fp32 if the plan ends
-        with an fc layer, else NCHW fp32 features."""
+    def forward(self, x: torch.Tensor, train: bool, drop_training: bool, u8_size=None):
+        """x: NCHW fp32 device tensor -- or, with ``u8_size = (H, W)``, decoded uint8 images [N][h][w][3] that
+        yolo_preprocess_u8 resizes + normalises straight into the stem's NHWC4 input buffer (no fp32 NCHW round trip).
+        Returns (out, saved) -- out is (N, O) fp32 if the plan ends with an fc layer, else NCHW fp32 features."""
         L_ = lib()
         st = stream()
         N = x.shape[0]
         dev = x.device
         x = x.detach()
-        if x.dtype != torch.float32 or not x.is_contiguous():
-            x = x.float().contiguous()
-        key, ws = self._workspace(N, x.shape, dev, train)
-        self._pack_all(train)
-        a = ws["in"]
-        if a.C == 4 and a.halo == 3:
-            check(L_.yolo_nchw_f32_to_nhwc_bf16(ptr(x), N, x.shape[1], x.shape[2], x.shape[3], a.p, 4, 3, 3, st), "nchw->nhwc4")
+        if u8_size is not None:
+            from . import preprocess as _pp
+            key, ws = self._workspace(N, (N, 3, u8_size[0], u8_size[1]), dev, train)
+            self._pack_all(train)
+            a = ws["in"]
+            if not (a.C == 4 and a.halo == 3):
+                raise ValueError("uint8 input needs a plan that starts with the 7x7/s2 stem")
+            _pp.preprocess_u8_into(x, u8_size, a)
         else:
-            check(L_.yolo_nchw_f32_to_nhwc_bf16(ptr(x), N, x.shape[1], x.shape[2], x.shape[3], a.p, a.C, 1, 1, st), "nchw->nhwc")
+            if x.dtype != torch.float32 or not x.is_contiguous():
+                x = x.float().contiguous()
+            key, ws = self._workspace(N, x.shape, dev, train)
+            self._pack_all(train)
+            a = ws["in"]
+            if a.C == 4 and a.halo == 3:
+                check(L_.yolo_nchw_f32_to_nhwc_bf16(ptr(x), N, x.shape[1], x.shape[2], x.shape[3], a.p, 4, 3, 3, st), "nchw->nhwc4")
+            else:
+                check(L_.yolo_nchw_f32_to_nhwc_bf16(ptr(x), N, x.shape[1], x.shape[2], x.shape[3], a.p, a.C, 1, 1, st), "nchw->nhwc")
         cur = a
         fc_saved = {}
         out = None

@@ -29,6 +29,7 @@ class _Preprocess:
 
     def __init__(self, size=(448, 448), mean=_MEAN, std=_STD):
         self.size = size
+        self.mean_t, self.std_t = tuple(mean), tuple(std)
         self.mean = torch.tensor(mean, dtype=torch.float32).view(3, 1, 1)
         self.std = torch.tensor(std, dtype=torch.float32).view(3, 1, 1)
 
@@ -61,6 +62,13 @@ class YOLOInference:
         return Image.open(image_path).convert("RGB")
 
     def preprocess_image(self, image: Image.Image) -> torch.Tensor:
+        if self._on_gpu() and isinstance(self.transform, _Preprocess) and image.mode == "RGB":
+            # device path: ship the decoded uint8 pixels (3 B each, not 12) and resize + normalise there --
+            # bit-identical to the host transform (yolo/preprocess.py)
+            from .preprocess import preprocess_u8
+            u8 = torch.from_numpy(np.asarray(image, dtype=np.uint8).copy()).unsqueeze(0).to(self.device)
+            out, _ = preprocess_u8(u8, self.transform.size, self.transform.mean_t, self.transform.std_t)
+            return out
         return self.transform(image).unsqueeze(0).to(self.device)
 
     def _on_gpu(self) -> bool:

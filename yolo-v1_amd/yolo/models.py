@@ -178,6 +178,16 @@ class YOLOv1(nn.Module):
             self._plan = engine.Plan.from_modules(list(self.backbone.features) + list(self.head), 3, True)
         return self._plan
 
+    @torch.no_grad()
+    def forward_uint8(self, images: torch.Tensor, size: tuple[int, int] = (448, 448)) -> torch.Tensor:
+        """Inference from decoded uint8 RGB images [N][H][W][3] on the device: Resize(size) + ToTensor + Normalize
+        (the reference's transform, inference.py:58-66, bit-exact) are done by yolo_preprocess_u8 straight into the stem's
+        input buffer -- extension of the reference surface for serving; equals ``self(transform(images))``."""
+        if not (images.is_cuda and self._fusable()):
+            raise RuntimeError("forward_uint8 needs device images and the default YOLOv1 backbone + head")
+        y, _ = self.hip_plan().forward(images, False, False, u8_size=size)
+        return y.view(-1, self.S, self.S, self.B * 5 + self.num_classes)
+
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         if x.is_cuda and self._fusable():
             y = engine.run_plan(self.hip_plan(), x, self.training)
