@@ -298,24 +298,47 @@ __global__ void __launch_bounds__(256, 2) wgrad_kernel(const WgradParams p)
         }
     }
 
-    // ---- output: D row (= co) = (reg&3) + 8*(reg>>2) + 4*(lane>>5), col (= ci) = lane&31.
-    // Per register the 32 lanes of a half write 128 contiguous bytes of one dw row.
+    // ---- output through LDS, one half of the co rows at a time ([64 co][128 ci] fp32 = stage A): the accumulator layout
+    // (row = (reg&3) + 8*(reg>>2) + 4*(lane>>5), col = lane&31) would give 4-B stores / atomics in 128-B pieces; from LDS
+    // a wave-instruction covers 1 KB of one dw row as 16-B stores, or 256 contiguous bytes per atomic instruction.
     const long ldw = (long)p.ntaps * p.Cin;
+    float *ot = reinterpret_cast<float *>(bufA);
+    const bool vec_ok = !atomic && (p.Cin & 3) == 0 && ((uintptr_t)p.dw & 15) == 0;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int h = 0; h < 2; ++h) {
+        __syncthreads();   // (first pass: every wave is done reading the stage buffers)
+        if (wco == h) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int ci = ci0 + wci * 64 + j * 32 + (lane & 31);
-            if (ci >= p.Cin) continue;
+            for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int co = co0 + wco * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (co >= p.Cout) continue;
-                float *o = p.dw + (long)co * ldw + (long)tap * p.Cin + ci;
-                if (atomic) atomicAdd(o, acc[i][j][r]);
-                else *o = acc[i][j][r];
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        ot[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * WG_T + wci * 64 + j * 32 + (lane & 31)] = acc[i][j][r];
+        }
+        __syncthreads();
+        if (vec_ok) {
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int idx = it * 256 + tid, row = idx >> 5, c4 = (idx & 31) * 4;
+                const int co = co0 + h * 64 + row, ci = ci0 + c4;
+                if (co < p.Cout && ci < p.Cin)   // Cin % 4 == 0: a quad is inside or outside as a whole
+                    *reinterpret_cast<float4 *>(p.dw + (long)co * ldw + (long)tap * p.Cin + ci) = *reinterpret_cast<const float4 *>(ot + row * WG_T + c4);
+            }
+        } else {
+#pragma unroll 4
+            for (int it = 0; it < 32; ++it) {
+                const int idx = it * 256 + tid, row = idx >> 7, c = idx & 127;
+                const int co = co0 + h * 64 + row, ci = ci0 + c;
+                if (co < p.Cout && ci < p.Cin) {
+                    float *o = p.dw + (long)co * ldw + (long)tap * p.Cin + ci;
+                    const float v = ot[row * WG_T + c];
+                    if (atomic) atomicAdd(o, v);
+                    else *o = v;
+                }
             }
         }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------
