@@ -337,6 +337,20 @@ int yolo_adam_step_multi(const yolo_adam_tensor *t, int count, float lr, float b
 int yolo_clip_scale_f32(float *g, long n, const double *norm_sq, float max_norm, yolo_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * TP / FP matching of mAPMetric on the device.  Replaces the per-class greedy matching loops of
+ * src/yolo/metrics.py:343-442 (AP per class and threshold), :444-491 (overall precision / recall) and :568-651 (size
+ * buckets), which walk every prediction in Python.  Inputs are the device outputs of yolo_decode + yolo_nms (metrics
+ * variant) and yolo_decode_gt of the same batch.  Per kept prediction k of image n (NMS output order):
+ *   tp_bits[n*max_per_img + k], bit v*(T+1) + t = 1 iff the prediction is a true positive at thresholds[t] against
+ *   ground-truth set v (0 all, 1 small, 2 medium, 3 large: area < small_area / < medium_area / else); t == T is
+ *   `extra_threshold` (the reference's overall precision / recall use 0.5 whatever the threshold list is).
+ * gt_bucket[n*max_gt + g] = 1 / 2 / 3.  thresholds is a HOST array.  T <= 15, max_per_img <= 128, max_gt <= 64. */
+int yolo_map_match(const double *rec, const int32_t *keep, const int32_t *keep_counts, int N, int max_per_img,
+                   const double *gt_rec, const int32_t *gt_counts, int max_gt, const double *thresholds, int T,
+                   double extra_threshold, double small_area, double medium_area, unsigned long long *tp_bits,
+                   int32_t *gt_bucket, yolo_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Image preprocessing.  Replaces YOLOInference.transform / the eval transform of the reference
  * (src/yolo/inference.py:58-66, src/yolo/dataset.py:224-233): Resize((Ho,Wo)) = PIL.Image.resize(BILINEAR) ->
  * ToTensor (/255) -> Normalize(mean, std), from decoded uint8 RGB [N][Hs][Ws][3] in device memory.

@@ -122,3 +122,41 @@ def test_other_grid_sizes(ops):
     keep, kc = ops.nms(torch.from_numpy(rec).cuda(), torch.from_numpy(cnt).cuda(), 0.4, 1)
     for n in range(3):
         assert np.array_equal(keep[n, : int(kc[n])].cpu().numpy(), O.nms(rec[n, : cnt[n]], 0.4, 1))
+
+
+def test_device_side_map_matching_equals_host_protocol():
+    """SURVEY 8f-3: mAPMetric with every update on the device -> TP/FP matching by yolo_map_match, compute() vectorised;
+    must give the SAME floats as the host protocol (the reference's greedy matching restated in yolo.metrics) on the same
+    accumulated lists -- all ~80 keys, incl. size buckets and overall precision / recall -- and handle images without
+    predictions or without ground truth."""
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden"))
+    import synth
+    from yolo.metrics import mAPMetric
+    rng = np.random.Generator(np.random.PCG64([3, 11]))
+    m = mAPMetric(num_classes=20, conf_threshold=0.2)
+    for b in range(3):
+        tgt = synth.synth_targets(16, seed=40 + b)
+        # predictions correlated with the targets (so that there are true positives at several thresholds) + noise
+        pred = rng.uniform(0, 0.35, size=(16, 7, 7, 30)).astype(np.float32)
+        obj = tgt[..., 4] > 0
+        pred[obj, :5] = tgt[obj, :5] + rng.normal(0, 0.03, size=(int(obj.sum()), 5)).astype(np.float32)
+        pred[obj, 5:10] = tgt[obj, :5] + rng.normal(0, 0.08, size=(int(obj.sum()), 5)).astype(np.float32)
+        pred[obj, 10:] = tgt[obj, 10:] * 0.9 + 0.05
+        if b == 1:
+            pred[3] = 0.0          # an image without predictions
+            tgt[5] = 0.0           # an image without ground truth
+        m.update(torch.from_numpy(pred).cuda(), torch.from_numpy(tgt).cuda())
+    assert m._dev_images == 48 == len(m.all_predictions)
+    fast = m.compute()
+    m._dev_images = -1             # force the host protocol on the very same lists
+    slow = m.compute()
+    assert fast.keys() == slow.keys() and len(fast) > 70
+    for k in fast:
+        assert fast[k] == slow[k], (k, fast[k], slow[k])
+    assert fast["mAP50"] > 0.3 and fast["num_small_objects"] + fast["num_medium_objects"] + fast["num_large_objects"] > 0
+    # lists filled by hand (the reference's own tests do that) fall back to the host protocol
+    m2 = mAPMetric(num_classes=20)
+    m2.all_predictions.append([(0, 0.9, (0.5, 0.5, 0.2, 0.2))])
+    m2.all_ground_truths.append([(0, (0.5, 0.5, 0.2, 0.2))])
+    assert abs(m2.compute()["mAP50"] - 1.0 / 20) < 1e-6

@@ -256,6 +256,82 @@ __global__ void __launch_bounds__(256) nms_kernel(const double *__restrict__ rec
     if (tid == 0) keep_counts[img] = nk;
 }
 
+// ------------------------------------------------------------------------------------------------
+// TP / FP matching of mAPMetric on the device (reference src/yolo/metrics.py:343-442, 568-651).
+// The reference sorts ALL predictions of a class by confidence and walks them, but a prediction only ever meets
+// the ground truths of its own image, and the kept list of an image (metrics NMS order: grouped by class,
+// confidence-descending, ties in scan order) is exactly that global order restricted to the image -- so the whole
+// greedy matching is per image.  One wavefront per image:
+//   1. every kept prediction finds its best ground truth (largest IoU > 0, first on ties, same class) in four
+//      ground-truth sets: all / small / medium / large (area limits of the reference's size metrics);
+//   2. lane l = (set v, threshold t) walks the predictions in order with its own `taken` bitmask over the <= 64
+//      ground truths: TP iff best_iou >= thr_t and that ground truth is still free.
+// Output per kept prediction: bit v*(T+1)+t of tp_bits (t == T: the extra threshold of the overall
+// precision / recall, set `all` only).  The host then only sorts, cumsums and interpolates (NumPy, vectorised).
+// ------------------------------------------------------------------------------------------------
+struct MapMatchParams {
+    double thr[16];
+    int T;
+    double small_t, medium_t;
+};
+
+__global__ void __launch_bounds__(64) map_match_kernel(const double *__restrict__ rec, const int *__restrict__ keep, const int *__restrict__ kcnt, int M,
+                                                       const double *__restrict__ grec, const int *__restrict__ gcnt, int G, const MapMatchParams prm,
+                                                       unsigned long long *__restrict__ tp_bits, int *__restrict__ gt_bucket)
+{
+    __shared__ double g_box[64][4];
+    __shared__ int g_cls[64], g_bkt[64];
+    __shared__ double b_iou[4][128];
+    __shared__ signed char b_gt[4][128];
+    __shared__ unsigned char hit[128][64];
+    const int img = blockIdx.x, lane = threadIdx.x;
+    const int nk = kcnt[img], ng = gcnt[img];
+    if (lane < ng) {
+        const double *g = grec + ((long)img * G + lane) * 5;
+        g_cls[lane] = (int)g[0];
+        g_box[lane][0] = g[1]; g_box[lane][1] = g[2]; g_box[lane][2] = g[3]; g_box[lane][3] = g[4];
+        const double area = g[3] * g[4];
+        const int b = area < prm.small_t ? 1 : (area < prm.medium_t ? 2 : 3);
+        g_bkt[lane] = b;
+        gt_bucket[(long)img * G + lane] = b;
+    }
+    __syncthreads();
+    for (int k = lane; k < nk; k += 64) {
+        const double *r = rec + ((long)img * M + keep[(long)img * M + k]) * 6;
+        const int c = (int)r[0];
+        double best[4] = {0.0, 0.0, 0.0, 0.0};
+        int bg[4] = {-1, -1, -1, -1};
+        for (int g = 0; g < ng; ++g) {
+            if (g_cls[g] != c) continue;
+            const double v = iou_f64<YOLO_NMS_METRICS>(r[2], r[3], r[4], r[5], g_box[g][0], g_box[g][1], g_box[g][2], g_box[g][3]);
+            if (v > best[0]) { best[0] = v; bg[0] = g; }           // strict '>': first maximum, and IoU must be > 0
+            const int b = g_bkt[g];
+            if (v > best[b]) { best[b] = v; bg[b] = g; }
+        }
+#pragma unroll
+        for (int v = 0; v < 4; ++v) { b_iou[v][k] = best[v]; b_gt[v][k] = (signed char)bg[v]; }
+    }
+    __syncthreads();
+    const int T1 = prm.T + 1;
+    if (lane < 4 * T1) {
+        const int v = lane / T1, t = lane - v * T1;
+        const double thr = prm.thr[t];
+        unsigned long long taken = 0ull;
+        for (int k = 0; k < nk; ++k) {
+            const int g = b_gt[v][k];
+            unsigned char h = 0;
+            if (g >= 0 && b_iou[v][k] >= thr && !((taken >> g) & 1ull)) { taken |= 1ull << g; h = 1; }
+            hit[k][lane] = h;
+        }
+    }
+    __syncthreads();
+    for (int k = lane; k < nk; k += 64) {
+        unsigned long long bits = 0ull;
+        for (int l = 0; l < 4 * T1; ++l) bits |= (unsigned long long)hit[k][l] << l;
+        tp_bits[(long)img * M + k] = bits;
+    }
+}
+
 }  // namespace yolo
 
 using namespace yolo;
@@ -304,4 +380,21 @@ YOLO_API int yolo_pairwise_iou(const double *a, int na, const double *b, int nb,
     else
         hipLaunchKernelGGL(pairwise_iou_kernel<YOLO_NMS_METRICS>, dim3(grid), dim3(256), 0, STRM(stream), a, na, b, nb, out);
     return check_launch("yolo_pairwise_iou");
+}
+
+YOLO_API int yolo_map_match(const double *rec, const int32_t *keep, const int32_t *keep_counts, int N, int max_per_img, const double *gt_rec, const int32_t *gt_counts,
+                            int max_gt, const double *thresholds, int T, double extra_threshold, double small_area, double medium_area,
+                            unsigned long long *tp_bits, int32_t *gt_bucket, yolo_stream_t stream)
+{
+    if (!rec || !keep || !keep_counts || !gt_rec || !gt_counts || !thresholds || !tp_bits || !gt_bucket || N <= 0) return fail(YOLO_E_ARG, "yolo_map_match: bad argument");
+    if (T < 1 || T > 15) return fail(YOLO_E_UNSUPPORTED, "yolo_map_match: 1..15 thresholds (got %d)", T);
+    if (max_per_img < 1 || max_per_img > 128 || max_gt < 1 || max_gt > 64)
+        return fail(YOLO_E_UNSUPPORTED, "yolo_map_match: at most 128 predictions and 64 ground truths per image (got %d, %d)", max_per_img, max_gt);
+    MapMatchParams prm{};
+    for (int t = 0; t < T; ++t) prm.thr[t] = thresholds[t];
+    prm.thr[T] = extra_threshold;
+    prm.T = T;
+    prm.small_t = small_area; prm.medium_t = medium_area;
+    hipLaunchKernelGGL(map_match_kernel, dim3(N), dim3(64), 0, STRM(stream), rec, keep, keep_counts, max_per_img, gt_rec, gt_counts, max_gt, prm, tp_bits, gt_bucket);
+    return check_launch("yolo_map_match");
 }

@@ -9,6 +9,12 @@ matching in confidence order, classes without ground truth or predictions contri
 
 One deliberate restructuring: the best-IoU ground truth of a prediction does not depend on the IoU
 threshold, so it is found once per class instead of once per (class, threshold).
+
+When every ``update`` ran on a ROCm device, the TP / FP matching itself (all classes, the 10 thresholds, the three
+size buckets and the overall precision / recall) is also done there, per image, by ``yolo_map_match`` -- a prediction
+only ever meets the ground truths of its own image, and an image's kept list is the global confidence order restricted
+to that image -- and ``compute`` reduces to sorts, cumulative sums and the 11-point interpolation in vectorised NumPy
+(same arithmetic, same floats as the host path, which remains for lists filled by hand or on the CPU).
 """
 
 from __future__ import annotations
@@ -55,10 +61,14 @@ class mAPMetric:
         self.B = B
         self.all_predictions: List[List[Pred]] = []
         self.all_ground_truths: List[List[GT]] = []
+        self._dev: List[tuple] = []      # per device batch: (cls, conf, tp_bits) of the kept predictions, (cls, bucket) of the GTs
+        self._dev_images = 0
 
     def reset(self):
         self.all_predictions = []
         self.all_ground_truths = []
+        self._dev = []
+        self._dev_images = 0
 
     # ------------------------------------------------------------------ accumulation
     def update(self, predictions: torch.Tensor, targets: torch.Tensor):
@@ -66,12 +76,27 @@ class mAPMetric:
         if predictions.is_cuda:
             from . import ops
             C = predictions.shape[-1] - 5 * self.B
-            per_img = ops.postprocess_host(predictions, self.conf_threshold, self.nms_threshold, ops._hip.NMS_METRICS, self.S, self.B, C)
+            rec, counts = ops.decode(predictions, self.conf_threshold, self.S, self.B, C)
+            keep, kc = ops.nms(rec, counts, self.nms_threshold, ops._hip.NMS_METRICS)
             grec, gcnt = ops.decode_gt(targets.to(predictions.device), self.S, self.B, C)
+            tp = bucket = None
+            T = len(self.iou_thresholds)
+            if T <= 15 and rec.shape[1] <= 128 and grec.shape[1] <= 64 and self._dev_images == len(self.all_predictions):
+                tp, bucket = ops.map_match(rec, keep, kc, grec, gcnt, self.iou_thresholds, 0.5, (32 / 448) ** 2, (96 / 448) ** 2)
+            rec_h, keep_h, kc_h = rec.cpu().numpy(), keep.cpu().numpy(), kc.cpu().numpy()      # (the batch's only device->host copies)
             grec, gcnt = grec.cpu().numpy(), gcnt.cpu().numpy()
-            for n, (rec, keep) in enumerate(per_img):
-                self.all_predictions.append(_records_to_preds(rec[keep]))
+            kept = [rec_h[n][keep_h[n, : kc_h[n]]] for n in range(rec_h.shape[0])]
+            for n, k in enumerate(kept):
+                self.all_predictions.append(_records_to_preds(k))
                 self.all_ground_truths.append(_records_to_gts(grec[n, : gcnt[n]]))
+            if tp is not None:
+                tp_h, bucket_h = tp.cpu().numpy().view(np.uint64), bucket.cpu().numpy()
+                allk = np.concatenate(kept) if kept else np.zeros((0, 6))
+                self._dev.append((allk[:, 0].astype(np.int64), allk[:, 1].copy(),
+                                  np.concatenate([tp_h[n, : kc_h[n]] for n in range(len(kept))]) if kept else np.zeros(0, np.uint64),
+                                  np.concatenate([grec[n, : gcnt[n], 0] for n in range(len(kept))]).astype(np.int64),
+                                  np.concatenate([bucket_h[n, : gcnt[n]] for n in range(len(kept))])))
+                self._dev_images += len(kept)
             return
         for i in range(predictions.shape[0]):
             self.all_predictions.append(self._apply_nms(self._parse_predictions(predictions[i])))
@@ -228,6 +253,9 @@ class mAPMetric:
         """mAP50:95 / mAP50 / mAP75, per-class AP, overall precision & recall at IoU 0.5, size buckets."""
         if len(self.all_predictions) == 0:
             return {"mAP50:95": 0.0, "mAP50": 0.0, "mAP75": 0.0, "precision": 0.0, "recall": 0.0}
+        if self._dev and self._dev_images == len(self.all_predictions) == len(self.all_ground_truths) \
+                and sum(len(d[0]) for d in self._dev) == sum(len(p) for p in self.all_predictions):
+            return self._compute_from_device_matches()
         results: Dict[str, float] = {}
         per_thr = {t: [] for t in self.iou_thresholds}
         for c in range(self.num_classes):
@@ -250,6 +278,84 @@ class mAPMetric:
         results["mAP50:95"] = np.mean([a for v in per_thr.values() for a in v])
         results["precision"], results["recall"] = self._calculate_overall_metrics(iou_threshold=0.5)
         results.update(self._compute_size_based_metrics())
+        return results
+
+
+    # ------------------------------------------------------------------ device-matched fast path
+    @staticmethod
+    def _ap_from_tp(tp: np.ndarray, n_gt: int) -> float:
+        """the arithmetic of _ap_at on a ready 0/1 vector (predictions already in confidence order)."""
+        fp = 1.0 - tp
+        ctp, cfp = np.cumsum(tp), np.cumsum(fp)
+        prec = np.concatenate(([1.0], ctp / (ctp + cfp + EPSILON)))
+        rec = np.concatenate(([0.0], ctp / n_gt))
+        ap = 0.0
+        for t in np.linspace(0, 1, 11):
+            sel = rec >= t
+            ap += (np.max(prec[sel]) if np.any(sel) else 0) / 11
+        return ap
+
+    def _compute_from_device_matches(self) -> Dict[str, float]:
+        cls = np.concatenate([d[0] for d in self._dev])
+        conf = np.concatenate([d[1] for d in self._dev])
+        bits = np.concatenate([d[2] for d in self._dev])
+        gcls = np.concatenate([d[3] for d in self._dev])
+        gbkt = np.concatenate([d[4] for d in self._dev])
+        T = len(self.iou_thresholds)
+        T1 = T + 1
+        # per class: the predictions in (stable) confidence order -- images and lists are already in the reference's order
+        order = {}
+        for c in range(self.num_classes):
+            idx = np.nonzero(cls == c)[0]
+            order[c] = idx[np.argsort(-conf[idx], kind="stable")]
+
+        def ap(c, v, t, n_gt):
+            o = order[c]
+            if n_gt == 0 or len(o) == 0:
+                return 0.0
+            return self._ap_from_tp(((bits[o] >> np.uint64(v * T1 + t)) & np.uint64(1)).astype(np.float64), n_gt)
+
+        results: Dict[str, float] = {}
+        per_thr = {t: [] for t in self.iou_thresholds}
+        for c in range(self.num_classes):
+            n_gt = int(np.count_nonzero(gcls == c))
+            aps = []
+            for ti, t in enumerate(self.iou_thresholds):
+                a = ap(c, 0, ti, n_gt)
+                per_thr[t].append(a)
+                aps.append(a)
+                if t == 0.5:
+                    results[f"AP50_class_{c}"] = a
+                elif t == 0.75:
+                    results[f"AP75_class_{c}"] = a
+            results[f"AP50:95_class_{c}"] = np.mean(aps)
+        if 0.5 in self.iou_thresholds:
+            results["mAP50"] = np.mean(per_thr[0.5])
+        if 0.75 in self.iou_thresholds:
+            results["mAP75"] = np.mean(per_thr[0.75])
+        results["mAP50:95"] = np.mean([a for v in per_thr.values() for a in v])
+        tp = int(np.count_nonzero((bits >> np.uint64(T)) & np.uint64(1)))      # set `all`, the extra 0.5 threshold
+        fp = len(bits) - tp
+        results["precision"], results["recall"] = tp / (tp + fp + EPSILON), tp / (len(gcls) + EPSILON)
+        for v, name in ((1, "small"), (2, "medium"), (3, "large")):
+            if not np.any(gbkt == v):
+                results[f"mAP50:95_{name}"] = 0.0
+                results[f"mAP50_{name}"] = 0.0
+                results[f"mAP75_{name}"] = 0.0
+                continue
+            pt = {t: [] for t in self.iou_thresholds}
+            for c in range(self.num_classes):
+                n_gt = int(np.count_nonzero((gcls == c) & (gbkt == v)))
+                for ti, t in enumerate(self.iou_thresholds):
+                    pt[t].append(ap(c, v, ti, n_gt))
+            if 0.5 in self.iou_thresholds:
+                results[f"mAP50_{name}"] = np.mean(pt[0.5])
+            if 0.75 in self.iou_thresholds:
+                results[f"mAP75_{name}"] = np.mean(pt[0.75])
+            results[f"mAP50:95_{name}"] = np.mean([a for vv in pt.values() for a in vv])
+        results["num_small_objects"] = int(np.count_nonzero(gbkt == 1))
+        results["num_medium_objects"] = int(np.count_nonzero(gbkt == 2))
+        results["num_large_objects"] = int(np.count_nonzero(gbkt == 3))
         return results
 
 

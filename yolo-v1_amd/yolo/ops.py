@@ -65,6 +65,22 @@ def pairwise_iou(a: torch.Tensor, b: torch.Tensor, variant: int) -> torch.Tensor
     return out
 
 
+def map_match(rec: torch.Tensor, keep: torch.Tensor, kc: torch.Tensor, grec: torch.Tensor, gcnt: torch.Tensor, thresholds, extra_thr: float,
+              small_area: float, medium_area: float):
+    """TP bits of every kept prediction (see yolo_map_match) + the size bucket of every ground truth, on the device.
+    Replaces the matching loops of src/yolo/metrics.py:343-442, 444-491, 568-651."""
+    import ctypes
+    _hip.require_cuda(rec, keep, kc, grec, gcnt)
+    N, M, _ = rec.shape
+    G = grec.shape[1]
+    tp = torch.zeros((N, M), dtype=torch.int64, device=rec.device)
+    bucket = torch.zeros((N, G), dtype=torch.int32, device=rec.device)
+    thr = (ctypes.c_double * len(thresholds))(*[float(t) for t in thresholds])
+    check(lib().yolo_map_match(ptr(rec), ptr(keep), ptr(kc), N, M, ptr(grec), ptr(gcnt), G, thr, len(thresholds), float(extra_thr), float(small_area),
+                               float(medium_area), ptr(tp), ptr(bucket), stream()), "yolo_map_match")
+    return tp, bucket
+
+
 def postprocess_host(pred: torch.Tensor, conf_thr: float, nms_thr: float, variant: int, S: int, B: int, C: int):
     """decode + NMS on the device for a batch, ONE device->host copy.
     Returns per image (rec[n] as a (cnt,6) float64 numpy array, kept indices int32 numpy array)."""
