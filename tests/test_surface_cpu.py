@@ -271,3 +271,21 @@ def test_predict_script_on_cpu(sample_image, capsys):
     finally:
         sys.argv = argv
     assert "detections" in capsys.readouterr().out
+
+
+def test_checkpoint_with_map_metrics_loads_with_weights_only(tmp_path):
+    """val_losses carries NumPy floats (np.mean of APs): the file must still load with torch.load(weights_only=True),
+    which evaluate.py / predict.py / --resume use."""
+    import numpy as np
+    import torch
+    import torch.nn as nn
+    from yolo.training import checkpoints
+    m = nn.Linear(4, 3)
+    opt = torch.optim.Adam(m.parameters())
+    sch = torch.optim.lr_scheduler.MultiStepLR(opt, [1])
+    val = {"total": np.float64(1.5), "mAP50:95": np.float64(0.25), "mAP50": np.float64(0.5), "mAP75": np.float64(0.125)}
+    checkpoints.save_checkpoint(tmp_path / "a.pth", 3, m, opt, sch, {"total": np.float32(2.0)}, val)
+    checkpoints.save_best_map_model(tmp_path / "b.pth", 3, m, opt, val, 0.25)
+    for f in ("a.pth", "b.pth"):
+        ck = torch.load(tmp_path / f, map_location="cpu", weights_only=True)
+        assert ck["epoch"] == 3 and ck["mAP50"] == 0.5 and type(ck["val_loss"]) is float
