@@ -243,10 +243,13 @@ int yolo_unpack_conv_wgrad(const float *dw_packed, int Cout, int Cin, int KH, in
  * (out_off = element offset of output pixel (0,0), pixel stride 64).  y = lrelu(conv + bias, slope); pool2 = 1 also
  * applies MaxPool2d(2,2) and out_* then address the POOLED map.  The raw input patch of an 8 x 16 output tile is staged
  * once in LDS and the 4x overlap of neighbouring pixels' 7 x 8 windows is resolved by the MFMA operand read addresses
- * (the generic yolo_igemm gathers every window from L2: 448 B per output pixel).  Ho % 8 == 0, Wo % 16 == 0. */
+ * (the generic yolo_igemm gathers every window from L2: 448 B per output pixel).  Ho % 8 == 0, Wo % 16 == 0.
+ * out_full (pool2 = 1 only, may be NULL): the un-pooled activation is written as well -- training needs it for the
+ * backward of the pool and of the LeakyReLU -- so that the separate pooling pass disappears there too. */
 int yolo_conv_stem7_fwd(const void *x_nhwc4_bf16, const void *w_packed_bf16, const float *bias, int N, int Ho, int Wo,
                         long x_img_stride, int x_row_stride, float slope, int pool2, void *out_bf16,
-                        long out_img_stride, int out_row_stride, int out_off, yolo_stream_t stream);
+                        long out_img_stride, int out_row_stride, int out_off, void *out_full_bf16,
+                        long full_img_stride, int full_row_stride, int full_off, yolo_stream_t stream);
 /* Weight + bias gradient of the 7x7 / stride-2 / pad-3 stem conv (models.py:49; 3 input channels stored
  * NHWC4 with halo 3, Cout = 64) WITHOUT the unfolded copy: the unfolding happens in the LDS read addresses of
  * the MFMA operands.  dy: NHWC bf16 with 64 channels, dy_off = element offset of output pixel (0,0).

@@ -14,7 +14,7 @@ b = torch.randn(64, device=dev)
 for pool in (1, 0):
     out = Act(N, 112 if pool else 224, 112 if pool else 224, 64, 1, dev)
     def run():
-        check(lib().yolo_conv_stem7_fwd(x.p, ptr(w), ptr(b), N, 224, 224, x.img_stride, x.row_stride, 0.1, pool, out.p, out.img_stride, out.row_stride, out.interior_off(), stream()))
+        check(lib().yolo_conv_stem7_fwd(x.p, ptr(w), ptr(b), N, 224, 224, x.img_stride, x.row_stride, 0.1, pool, out.p, out.img_stride, out.row_stride, out.interior_off(), None, 0, 0, 0, stream()))
     for _ in range(3): run()
     e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
     e0.record()

@@ -44,6 +44,9 @@ struct StemFwdParams {
     int x_row_stride, out_row_stride, out_off;
     int pool;
     float slope;
+    bf16_t *full;           // pool mode only, optional: the un-pooled activation as well (training keeps it for the backward pass)
+    long full_img_stride;
+    int full_row_stride, full_off;
 };
 
 __global__ void __launch_bounds__(256, 2) stem_fwd_kernel(const StemFwdParams p)
@@ -149,6 +152,15 @@ __global__ void __launch_bounds__(256, 2) stem_fwd_kernel(const StemFwdParams p)
                 o[k] = (__float_as_uint(lo) >> 16) | (__float_as_uint(hi) & 0xffff0000u);
             }
             *reinterpret_cast<uint4 *>(ob + (long)(ty * (SF_TH / 2) + qy) * p.out_row_stride + (tx * (SF_TW / 2) + qx) * 64 + c8 * 8) = uint4{o[0], o[1], o[2], o[3]};
+            if (p.full) {
+                bf16_t *fb = p.full + (long)n * p.full_img_stride + p.full_off;
+#pragma unroll
+                for (int pass = 0; pass < 4; ++pass) {
+                    const int idx = pass * 256 + tid, cc = idx & 7, px = idx >> 3;
+                    const uint4 v = *reinterpret_cast<const uint4 *>(otile + px * SF_OP + cc * 8);
+                    *reinterpret_cast<uint4 *>(fb + (long)(ty * SF_TH + (px >> 4)) * p.full_row_stride + (tx * SF_TW + (px & 15)) * 64 + cc * 8) = v;
+                }
+            }
         } else {
 #pragma unroll
             for (int pass = 0; pass < 4; ++pass) {
@@ -201,8 +213,11 @@ __global__ void __launch_bounds__(256, 2) stem_fwd_kernel(const StemFwdParams p)
 using namespace yolo;
 
 YOLO_API int yolo_conv_stem7_fwd(const void *x_nhwc4, const void *w_packed, const float *bias, int N, int Ho, int Wo, long x_img_stride, int x_row_stride,
-                                 float slope, int pool2, void *out, long out_img_stride, int out_row_stride, int out_off, yolo_stream_t stream)
+                                 float slope, int pool2, void *out, long out_img_stride, int out_row_stride, int out_off, void *out_full, long full_img_stride,
+                                 int full_row_stride, int full_off, yolo_stream_t stream)
 {
+    if (out_full && (!pool2 || (full_row_stride & 7) || (full_img_stride & 7) || (full_off & 7) || ((uintptr_t)out_full & 15)))
+        return fail(YOLO_E_ARG, "yolo_conv_stem7_fwd: out_full needs pool2 = 1 and strides in multiples of 8 elements");
     if (!x_nhwc4 || !w_packed || !bias || !out || N <= 0 || Ho <= 0 || Wo <= 0) return fail(YOLO_E_ARG, "yolo_conv_stem7_fwd: bad argument");
     if ((Ho % SF_TH) || (Wo % SF_TW)) return fail(YOLO_E_UNSUPPORTED, "yolo_conv_stem7_fwd: output %dx%d is not a multiple of %dx%d (use yolo_igemm)", Ho, Wo, SF_TH, SF_TW);
     if ((x_row_stride & 7) || (x_img_stride & 7) || (out_row_stride & 7) || (out_img_stride & 7) || (out_off & 7) || ((uintptr_t)x_nhwc4 & 15) || ((uintptr_t)out & 15) ||
@@ -218,6 +233,7 @@ YOLO_API int yolo_conv_stem7_fwd(const void *x_nhwc4, const void *w_packed, cons
     p.x_row_stride = x_row_stride; p.out_row_stride = out_row_stride; p.out_off = out_off;
     p.pool = pool2 ? 1 : 0;
     p.slope = slope;
+    p.full = (bf16_t *)out_full; p.full_img_stride = full_img_stride; p.full_row_stride = full_row_stride; p.full_off = full_off;
     // persistent workgroups, 2 resident per CU (200 VGPRs): 512 .. 2048 measure the same
     const long G = std::min<long>(nt, 1024);
     hipLaunchKernelGGL(stem_fwd_kernel, dim3((unsigned)G), dim3(256), 0, STRM(stream), p);

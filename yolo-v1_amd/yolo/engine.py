@@ -577,13 +577,18 @@ class Plan:
                 d.pool2 = 1 if fuse else 0
                 b = L.bias.detach()
                 if L.first and STEM_KERNEL and L.Cout == 64 and L.Hout % 8 == 0 and L.Wout % 16 == 0 and nxt.C == 64 and b.dtype == torch.float32:
-                    # dedicated stem kernel: input patch staged once per 8x16 tile, weights in registers
-                    with _timed(f"conv{li}" + ("+pool" if fuse else ""), "stem", 2.0 * N * L.Hout * L.Wout * L.Cout * L.Cin * L.K * L.K):
+                    # dedicated stem kernel: input patch staged once per 8x16 tile, weights in registers; in training the
+                    # following MaxPool2d is fused as well, with the un-pooled activation written next to the pooled one
+                    dual = (train and FUSE_POOL and li + 1 < len(self.layers) and self.layers[li + 1].kind == "pool")
+                    full = nxt if dual else None
+                    dst = ws["acts"][li + 1] if dual else nxt
+                    with _timed(f"conv{li}" + ("+pool" if (fuse or dual) else ""), "stem", 2.0 * N * L.Hout * L.Wout * L.Cout * L.Cin * L.K * L.K):
                         check(L_.yolo_conv_stem7_fwd(cur.p, ptr(wf), ptr(b), N, L.Hout, L.Wout, cur.img_stride, cur.row_stride,
-                                                     self.SLOPE if L.lrelu else 1.0, 1 if fuse else 0, nxt.p, nxt.img_stride, nxt.row_stride,
-                                                     nxt.interior_off(), st), "conv_stem7_fwd")
-                    cur = nxt
-                    skip_pool = fuse
+                                                     self.SLOPE if L.lrelu else 1.0, 1 if (fuse or dual) else 0, dst.p, dst.img_stride, dst.row_stride,
+                                                     dst.interior_off(), full.p if dual else None, full.img_stride if dual else 0,
+                                                     full.row_stride if dual else 0, full.interior_off() if dual else 0, st), "conv_stem7_fwd")
+                    cur = dst
+                    skip_pool = fuse or dual
                     continue
                 with _timed(f"conv{li}" + ("+pool" if fuse else ""), "igemm", 2.0 * N * L.Hout * L.Wout * L.Cout * L.Cin * L.K * L.K):
                     igemm_call(d, cur.p, ptr(wf), ptr(b), None, nxt.p, st, f"igemm conv{li}")
@@ -1099,7 +1104,7 @@ class ResNetPlan:
         if STEM_KERNEL and Ho % 8 == 0 and Wo % 16 == 0:
             with _timed("stem", "stem", 2.0 * N * Ho * Wo * 64 * 147):
                 check(lib().yolo_conv_stem7_fwd(a.p, ptr(wf), ptr(b), N, Ho, Wo, a.img_stride, a.row_stride, 0.0, 0, s1.p, s1.img_stride, s1.row_stride,
-                                                s1.interior_off(), st), "conv_stem7_fwd")
+                                                s1.interior_off(), None, 0, 0, 0, st), "conv_stem7_fwd")
         else:
             with _timed("stem", "igemm", 2.0 * N * Ho * Wo * 64 * 147):
                 _igemm(lib(), d, a.p, ptr(wf), ptr(b), None, s1.p, st, "igemm stem")
