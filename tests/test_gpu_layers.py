@@ -297,6 +297,32 @@ def test_stem_wgrad_direct_kernel():
                                   ptr(dw2), ptr(db2), ptr(part), part.numel(), stream()) != 0
 
 
+def test_wgrad_kernel_variants_agree_bit_for_bit():
+    """yolo_wgrad: the 128x128 kernel, the 256x128 3-stage kernel and its staggered two-phase form reduce every output over
+    the pixels in the same order (16-pixel MFMA sub-steps), so with one pixel range per tile they must agree bit for bit --
+    weights and fused bias gradient; ragged pixel count, 3x3 taps, several tiles."""
+    import ctypes
+    from yolo._hip import WgradDesc, check, lib, ptr, stream
+    from yolo.engine import Act
+    torch.manual_seed(21)
+    N, H, W, Cin, Cout = 3, 9, 11, 192, 512
+    x = Act(N, H, W, Cin, 1, torch.device("cuda")); dy = Act(N, H, W, Cout, 1, torch.device("cuda"))
+    x.interior().copy_(torch.randn(N, H, W, Cin, device="cuda").to(torch.bfloat16))
+    dy.interior().copy_((torch.randn(N, H, W, Cout, device="cuda") * 0.1).to(torch.bfloat16))
+    outs = []
+    for variant in (1, 2, 3):
+        dw = torch.full((Cout, 3, 3, Cin), float("nan"), device="cuda")
+        db = torch.zeros(Cout, device="cuda")
+        wd = WgradDesc(dy.slots, dy.px_stride, x.px_stride, Cout, Cin, 3, 3, 1, x.row_stride, 1, 0, variant)
+        check(lib().yolo_wgrad(ctypes.byref(wd), x.p, dy.p, ptr(dw), ptr(db), stream()))
+        outs.append((dw, db))
+    ref = torch.einsum("nhwo,nhwkc->okc", dy.interior().float(),
+                       torch.stack([x.view()[:, ky: ky + H, kx: kx + W, :].float() for ky in range(3) for kx in range(3)], dim=3)).view(Cout, 3, 3, Cin)
+    torch.testing.assert_close(outs[0][0], ref, rtol=2e-3, atol=2e-3)
+    for dw, db in outs[1:]:
+        assert torch.equal(dw, outs[0][0]) and torch.equal(db, outs[0][1])
+
+
 def test_fc_dgrad_behind_flatten_matches_cpu():
     """Linear behind nn.Flatten: the data gradient goes through yolo_wgrad (transposed product) + yolo_fc_dgrad_to_nhwc."""
     torch.manual_seed(5)

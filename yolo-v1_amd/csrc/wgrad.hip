@@ -51,7 +51,7 @@ struct WgradParams {
     // two-segment schedule (seg = 1, 1-D grid): the first main_tiles tiles are split into main_split pixel ranges and fill
     // whole rounds of the chip's 512 workgroup slots; the remaining tail_tiles (< 512 / main_split) tiles are split finer
     // (tail_split ranges) so that they fill one more, shorter round instead of leaving most CUs idle for a full-length one
-    int seg;
+    int seg, slots;         // slots: resident workgroups on the chip (512 for the 128x128 kernel, 256 for the 256x128 ones)
     int main_tiles, main_split, tail_tiles, tail_split;
     long per_main, per_tail;
 };
@@ -65,14 +65,14 @@ __device__ __forceinline__ void wgrad_map(const WgradParams &p, int nwg, int &bi
 {
     atomic = p.atomic & 1;
     if (p.seg) {
-        const int id = blockIdx.x;
-        const int L = (id & ~(WG_SLOTS - 1)) | ((id & 7) << 6) | ((id >> 3) & 63);
+        const int id = blockIdx.x, per_xcd = p.slots >> 3;
+        const int L = id / p.slots * p.slots + (id & 7) * per_xcd + ((id % p.slots) >> 3);
         const int nmain = p.main_tiles * p.main_split;
         int range;
         long per;
         if (L < nmain) {
-            const int tpr = WG_SLOTS / p.main_split;          // tiles per round
-            const int round = L / WG_SLOTS, within = L % WG_SLOTS;
+            const int tpr = p.slots / p.main_split;           // tiles per round
+            const int round = L / p.slots, within = L % p.slots;
             range = within / tpr;
             bid = round * tpr + within % tpr;
             per = p.per_main;
@@ -355,6 +355,7 @@ constexpr int W2_A_BYTES = WG_BP * W2_TCO * 2;     // 32 KB
 constexpr int W2_B_BYTES = WG_BP * W2_TCI * 2;     // 16 KB
 constexpr int W2_STAGE = W2_A_BYTES + W2_B_BYTES;  // 48 KB
 
+template <bool STG>
 __global__ void __launch_bounds__(512, 1) wgrad256_kernel(const WgradParams p)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];   // 3 stages x 48 KB
@@ -454,6 +455,77 @@ __global__ void __launch_bounds__(512, 1) wgrad256_kernel(const WgradParams p)
     const long nsteps = pbeg < pend ? (pend - pbeg + WG_BP - 1) / WG_BP : 0;
     auto run = [&](auto bias_tag) {
         constexpr bool BIAS = decltype(bias_tag)::value;
+        if constexpr (STG) {
+            // ---- staggered two-phase schedule (the one of igemm.hip's MFMA_16x16x32_STAGGER): every K step is an L phase (all
+            // 32 transposing reads of the step -> registers) and an M phase (its 16 MFMAs) between raw barriers; waves 0..3 and
+            // 4..7 sit pairwise on the same SIMDs and run ONE PHASE APART, so one wave feeds the matrix pipe while its partner
+            // reads LDS.  Stage s is issued by everybody in slot 2(s-2) and drained (counted vmcnt) at the end of slot 2s-1.
+            auto read_all = [&](int st, WFrag (&f)[4]) {
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) wave_load<BIAS>(smem + st * W2_STAGE, a_rd, b_rd, ks * 8192, 2048, ks * 4096, 1024, f[ks], bsum);
+            };
+            auto mfma_all = [&](WFrag (&f)[4]) {
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[ks].a[i], f[ks].b[j], acc[i][j], 0, 0, 0);
+            };
+            auto wait_stage = [&](long newer) {   // newer = younger stages this wave has already issued
+                if (newer >= 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            };
+#define W2_BAR()                                   \
+    do {                                           \
+        __builtin_amdgcn_sched_barrier(0);         \
+        __builtin_amdgcn_s_barrier();              \
+        __builtin_amdgcn_sched_barrier(0);         \
+    } while (0)
+            const bool grpB = wave >= 4;
+            const long nkk = nsteps;
+            if (nkk > 0) stage(0, pbeg);
+            if (nkk > 1) stage(1, pbeg + WG_BP);
+            wait_stage(nkk - 1 < 1 ? nkk - 1 : 1);
+            W2_BAR();
+            WFrag f[4];
+            int rd = 0;
+            if (!grpB) {
+                int ld = 2;
+                for (long it = 0; it < nkk; ++it) {
+                    read_all(rd, f);                                                    // L(it)
+                    if (it + 2 < nkk) stage(ld, pbeg + (it + 2) * WG_BP);
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    W2_BAR();
+                    __builtin_amdgcn_s_setprio(1);
+                    mfma_all(f);                                                        // M(it)
+                    __builtin_amdgcn_s_setprio(0);
+                    { const long left = nkk - 2 - it; wait_stage(left < 0 ? 0 : left); }   // stage it+1 landed
+                    W2_BAR();
+                    rd = rd + 1 == 3 ? 0 : rd + 1;
+                    ld = ld + 1 == 3 ? 0 : ld + 1;
+                }
+                __builtin_amdgcn_s_barrier();
+            } else {
+                if (2 < nkk) stage(2, pbeg + 2 * WG_BP);                                // slot 0
+                W2_BAR();
+                int ld = 0;
+                for (long it = 0; it < nkk; ++it) {
+                    read_all(rd, f);                                                    // L(it)
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    { const long left = nkk - 2 - it; wait_stage(left < 0 ? 0 : left); }
+                    W2_BAR();
+                    if (it + 3 < nkk) stage(ld, pbeg + (it + 3) * WG_BP);               // M(it)
+                    __builtin_amdgcn_s_setprio(1);
+                    mfma_all(f);
+                    __builtin_amdgcn_s_setprio(0);
+                    W2_BAR();
+                    rd = rd + 1 == 3 ? 0 : rd + 1;
+                    ld = ld + 1 == 3 ? 0 : ld + 1;
+                }
+            }
+#undef W2_BAR
+        } else {
         if (nsteps > 0) stage(0, pbeg);
         if (nsteps > 1) stage(1, pbeg + WG_BP);
         for (long t = 0; t < nsteps; t += 3) {
@@ -468,6 +540,7 @@ __global__ void __launch_bounds__(512, 1) wgrad256_kernel(const WgradParams p)
             W2_SYNC(t + 3 < nsteps);
             if (t + 4 < nsteps) stage(1, pbeg + (t + 4) * WG_BP);
             wave_step<BIAS, 8192, 2048, 4096, 1024>(smem + 2 * W2_STAGE, a_rd, b_rd, acc, bsum);
+        }
         }
     };
     if (do_bias) run(std::true_type{});
@@ -746,7 +819,7 @@ YOLO_API int yolo_wgrad(const yolo_wgrad_desc *d, const void *x, const void *dy,
         if (d->geo_W < 0 || d->geo_H < 0 || (d->geo_W > 0 && (d->geo_H <= 0 || d->geo_W > 65536 || d->geo_H > 65536)))
             return fail(YOLO_E_ARG, "yolo_wgrad: bad pixel geometry %d x %d", d->geo_W, d->geo_H);
         if (d->geo_W > 0) {
-            if (d->variant == 2) return fail(YOLO_E_UNSUPPORTED, "yolo_wgrad: variant 2 has no pixel-geometry mode");
+            if (d->variant == 2 || d->variant == 3) return fail(YOLO_E_UNSUPPORTED, "yolo_wgrad: the 256x128 variants have no pixel-geometry mode");
             if (d->P % ((long)d->geo_W * d->geo_H)) return fail(YOLO_E_ARG, "yolo_wgrad: P = %ld is not a whole number of %d x %d images", (long)d->P, d->geo_W, d->geo_H);
             p.gW = d->geo_W; p.gH = d->geo_H;
             p.g_img = d->geo_img_slots; p.g_row = d->geo_row_slots; p.g_px = d->geo_px_slots; p.g_off = d->geo_slot0;
@@ -764,7 +837,7 @@ YOLO_API int yolo_wgrad(const yolo_wgrad_desc *d, const void *x, const void *dy,
         const long steps_total = (d->P + WG_BP - 1) / WG_BP;
         // kernel variant: 256-wide co tiles (8 waves, 3 stages) only on request (d->variant == 2): measured no faster
         // than two co-resident 128 x 128 workgroups on any layer of the model
-        const bool big = d->variant == 2;
+        const bool big = d->variant == 2 || d->variant == 3;   // 3: + staggered two-phase schedule
         p.n_co_tiles = big ? (d->Cout + W2_TCO - 1) / W2_TCO : (d->Cout + WG_T - 1) / WG_T;
         const int tiles = p.n_co_tiles * p.n_ci_tiles * p.ntaps;
         dim3 grid;
@@ -794,6 +867,7 @@ YOLO_API int yolo_wgrad(const yolo_wgrad_desc *d, const void *x, const void *dy,
             }
             const int tpr = slots / bs;
             p.seg = 1;
+            p.slots = slots;
             p.main_split = bs;
             p.main_tiles = tiles / tpr * tpr;
             p.tail_tiles = tiles - p.main_tiles;
@@ -804,16 +878,18 @@ YOLO_API int yolo_wgrad(const yolo_wgrad_desc *d, const void *x, const void *dy,
             // or holds the value to add to: accumulate forces atomics everywhere)
             p.atomic = d->accumulate ? 3 : ((bs > 1 ? 1 : 0) | (p.tail_split > 1 ? 2 : 0));
             const long nblk = (long)p.main_tiles * bs + (long)p.tail_tiles * p.tail_split;
-            grid = dim3((unsigned)((nblk + WG_SLOTS - 1) / WG_SLOTS * WG_SLOTS));   // whole groups of 512 ids for the XCD map
+            grid = dim3((unsigned)((nblk + slots - 1) / slots * slots));   // whole groups of `slots` ids for the XCD map
         }
         if (big) {
             static bool lds_ok = false;
             if (!lds_ok) {
-                hipError_t e = hipFuncSetAttribute((const void *)wgrad256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * W2_STAGE);
+                hipError_t e = hipFuncSetAttribute((const void *)wgrad256_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * W2_STAGE);
+                if (e == hipSuccess) e = hipFuncSetAttribute((const void *)wgrad256_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * W2_STAGE);
                 if (e != hipSuccess) return fail((int)e, "yolo_wgrad: hipFuncSetAttribute(%d B LDS): %s", 3 * W2_STAGE, hipGetErrorString(e));
                 lds_ok = true;
             }
-            hipLaunchKernelGGL(wgrad256_kernel, grid, dim3(512), 3 * W2_STAGE, s, p);
+            if (d->variant == 3) hipLaunchKernelGGL(wgrad256_kernel<true>, grid, dim3(512), 3 * W2_STAGE, s, p);
+            else hipLaunchKernelGGL(wgrad256_kernel<false>, grid, dim3(512), 3 * W2_STAGE, s, p);
         } else {
             hipLaunchKernelGGL(wgrad_kernel, grid, dim3(256), 0, s, p);
         }
