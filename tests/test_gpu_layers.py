@@ -323,6 +323,31 @@ def test_wgrad_kernel_variants_agree_bit_for_bit():
         assert torch.equal(dw, outs[0][0]) and torch.equal(db, outs[0][1])
 
 
+def test_stride2_data_gradient_by_parity_classes():
+    """3x3 / stride-2 conv backward: four parity-class convs over the non-zero gradient slots (engine.STRIDE2_CLASSES) vs the
+    plain data gradient over the zero-stuffed buffer vs the bf16-faithful CPU reference."""
+    from yolo import engine
+    torch.manual_seed(8)
+    mods = nn.Sequential(nn.Conv2d(64, 128, 3, 1, 1), nn.LeakyReLU(0.1), nn.Conv2d(128, 256, 3, 2, 1), nn.LeakyReLU(0.1),
+                         nn.Conv2d(256, 64, 3, 1, 1), nn.LeakyReLU(0.1)).eval()
+    x = torch.randn(3, 64, 12, 10)
+    gy = torch.randn(3, 64, 6, 5)
+    import copy
+    res = {}
+    for flag in (True, False):
+        engine.STRIDE2_CLASSES = flag
+        try:
+            res[flag] = _run_both(copy.deepcopy(mods), x, gy)      # fresh copy: the CPU side accumulates .grad
+        finally:
+            engine.STRIDE2_CLASSES = True
+    yc, yg, gc, gg = res[True]
+    names = ["dx"] + [n for n, _ in mods.named_parameters()]
+    for n, a, b in zip(names, gg, gc):
+        _close(a, b, 6.0, f"classes vs cpu: {n}", frac=0.01)
+    for n, a, b in zip(names, gg, res[False][3]):
+        _close(a, b, 2.0, f"classes vs zero-stuffed: {n}", frac=0.005)
+
+
 def test_fc_dgrad_behind_flatten_matches_cpu():
     """Linear behind nn.Flatten: the data gradient goes through yolo_wgrad (transposed product) + yolo_fc_dgrad_to_nhwc."""
     torch.manual_seed(5)

@@ -39,6 +39,7 @@ TIMERS: list | None = None
 TILE_HINT = 0
 IGEMM_LAUNCHES = 0  # yolo_igemm launches so far (bench.py: launches per step of the dominant kernel)
 STEM_KERNEL = True  # 7x7/s2 stem through yolo_conv_stem7_fwd (False: the generic row-segment implicit GEMM; tests compare)
+STRIDE2_CLASSES = True  # data gradient of a stride-2 3x3 conv as four parity-class convs over the non-zero gradient slots
 FUSE_POOL = True   # inference: fold MaxPool2d(2,2) into the preceding conv's epilogue where the geometry allows
 
 
@@ -265,6 +266,7 @@ class Plan:
         self._pf: dict[int, tuple] = {}
         self._pd: dict[int, tuple] = {}
         self._pfb: dict[int, tuple] = {}
+        self._pd2: dict[int, tuple] = {}
         self._ws: dict[tuple, list] = {}
         self.debug_keep = False      # tests: keep the last workspace (activations + gradients) for inspection
         self.last = None
@@ -443,6 +445,22 @@ class Plan:
             self._pd[li] = (key, wd)
             return wf, wd
         return wf, (wd if ok_d else None)
+
+    def _stride2_panels(self, li: int, wdg: torch.Tensor) -> dict:
+        """data-gradient operands of a stride-2 3x3 conv by input-pixel parity: slices of the flipped panel
+        wd[ci][ky'][kx'][co] (ky' = 2 - ky): parity 0 uses ky' = 1, parity 1 uses ky' = 0 (tap offset 0) and 2 (offset 1)."""
+        L = self.layers[li]
+        key = self._wkey(L.weight)
+        hit = self._pd2.get(li)
+        if hit is not None and hit[0] == key:
+            return hit[1]
+        sel = {0: slice(1, 2), 1: slice(0, 3, 2)}      # basic slices: one strided copy per class, no gather kernels
+        panels = {}
+        for py in (0, 1):
+            for px in (0, 1):
+                panels[(py, px)] = wdg[:, sel[py], sel[px], :].contiguous()
+        self._pd2[li] = (key, panels)
+        return panels
 
     def _pack_fc_blocked(self, li: int):
         """inference operand of a Linear layer: bf16 [O/128][K/64][128][64] panels (contiguous 16-KB stage reads; the
@@ -911,7 +929,35 @@ class Plan:
                 d.stride, d.KH, d.KW, d.tap_len, d.Cout = 1, L.K, L.K, L.Cout, L.Cin
                 d.slope, d.out_fp32, d.split_k = self.SLOPE, 0, 1
                 d.tile_hint = TILE_HINT
-                if prev.kind == "conv":
+                if (prev.kind == "conv" and STRIDE2_CLASSES and L.stride == 2 and L.K == 3 and L.pad == 1 and prev.stride == 1
+                        and L.Hin % 2 == 0 and L.Win % 2 == 0):
+                    # stride-2 3x3 conv: the gradient buffer g holds dy zero-stuffed to the input grid, and the plain data gradient
+                    # spends 3/4 of its MACs on those zeros.  By input-pixel parity (py, px) only the taps ky = 1 (py even) or
+                    # ky = 2, 0 (py odd; likewise kx) contribute: four small convs over the NON-ZERO slots (doubled input strides)
+                    # with 1, 2, 2 and 4 taps -- 9 taps per 2x2 input pixels instead of 36 -- each writing its parity class of the
+                    # previous layer's gradient (doubled output strides).
+                    gp = self._grad_buf(ws, li - 1, N, dev)
+                    yprev = ws["acts"][li - 1]
+                    panels = self._stride2_panels(li, wdg)
+                    with _timed(f"conv{li}.dgrad", "igemm", 2.0 * N * L.Hout * L.Wout * L.Cout * L.Cin * L.K * L.K):
+                        for (py, px), wc in panels.items():
+                            dc = IgemmDesc()
+                            dc.N, dc.Ho, dc.Wo = N, L.Hin // 2, L.Win // 2
+                            dc.in_img_stride, dc.in_row_stride, dc.in_px_stride, dc.in_off = g.img_stride, 2 * g.row_stride, 2 * g.px_stride, g.interior_off()
+                            dc.stride, dc.KH, dc.KW, dc.tap_len, dc.Cout = 1, 1 + py, 1 + px, L.Cout, L.Cin
+                            dc.slope, dc.out_fp32, dc.split_k, dc.tile_hint = self.SLOPE, 0, 1, TILE_HINT
+                            dc.out_img_stride, dc.out_row_stride, dc.out_px_stride = gp.img_stride, 2 * gp.row_stride, 2 * gp.px_stride
+                            dc.out_off = gp.interior_off() + py * gp.row_stride + px * gp.px_stride
+                            aux = None
+                            dc.epilogue = EPI_NONE
+                            if prev.lrelu:
+                                dc.epilogue = EPI_MUL_DLRELU
+                                dc.aux_img_stride, dc.aux_row_stride, dc.aux_px_stride = yprev.img_stride, 2 * yprev.row_stride, 2 * yprev.px_stride
+                                dc.aux_off = yprev.interior_off() + py * yprev.row_stride + px * yprev.px_stride
+                                aux = yprev.p
+                            igemm_call(dc, g.p, ptr(wc), None, aux, gp.p, st, f"dgrad conv{li} class {py}{px}")
+                    g_act = gp
+                elif prev.kind == "conv":
                     gp = self._grad_buf(ws, li - 1, N, dev)
                     d.out_img_stride, d.out_row_stride, d.out_px_stride, d.out_off = self._grad_out_strides(prev, gp)
                     yprev = ws["acts"][li - 1]
