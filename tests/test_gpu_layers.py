@@ -297,7 +297,8 @@ def test_stem_wgrad_direct_kernel():
                                   ptr(dw2), ptr(db2), ptr(part), part.numel(), stream()) != 0
 
 
-def test_wgrad_kernel_variants_agree_bit_for_bit():
+@pytest.mark.parametrize("Cin", [192, 64])
+def test_wgrad_kernel_variants_agree_bit_for_bit(Cin):
     """yolo_wgrad: the 128x128 kernel, the 256x128 3-stage kernel and its staggered two-phase form reduce every output over
     the pixels in the same order (16-pixel MFMA sub-steps), so with one pixel range per tile they must agree bit for bit --
     weights and fused bias gradient; ragged pixel count, 3x3 taps, several tiles."""
@@ -305,7 +306,7 @@ def test_wgrad_kernel_variants_agree_bit_for_bit():
     from yolo._hip import WgradDesc, check, lib, ptr, stream
     from yolo.engine import Act
     torch.manual_seed(21)
-    N, H, W, Cin, Cout = 3, 9, 11, 192, 512
+    N, H, W, Cout = 3, 9, 11, 512          # Cin = 64: the 128 x 128 kernel packs two taps per tile (pair_taps), the others do not
     x = Act(N, H, W, Cin, 1, torch.device("cuda")); dy = Act(N, H, W, Cout, 1, torch.device("cuda"))
     x.interior().copy_(torch.randn(N, H, W, Cin, device="cuda").to(torch.bfloat16))
     dy.interior().copy_((torch.randn(N, H, W, Cout, device="cuda") * 0.1).to(torch.bfloat16))

@@ -47,6 +47,8 @@ struct WgradParams {
     int KH, KW, pad;
     long x_row_stride;
     int n_co_tiles, n_ci_tiles, ntaps;
+    int pair_taps;          // Cin == 64 (128 x 128 kernel): a ci-tile holds TWO taps (columns 0..63 / 64..127 are adjacent in
+                            // dw[co][tap][ci]), so half the tile is not wasted on padding; tile index = pair index then
     int atomic;             // uniform split: accumulate with atomics.  Two-segment schedule: bit 0 = main segment, bit 1 = tail
     // two-segment schedule (seg = 1, 1-D grid): the first main_tiles tiles are split into main_split pixel ranges and fill
     // whole rounds of the chip's 512 workgroup slots; the remaining tail_tiles (< 512 / main_split) tiles are split finer
@@ -168,7 +170,8 @@ __global__ void __launch_bounds__(256, 2) wgrad_kernel(const WgradParams p)
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wco = wave >> 1, wci = wave & 1;
 
-    const int nwg = p.n_co_tiles * p.n_ci_tiles * p.ntaps;
+    const int ntap_tiles = p.pair_taps ? (p.ntaps + 1) / 2 : p.ntaps;
+    const int nwg = p.n_co_tiles * p.n_ci_tiles * ntap_tiles;
     int bid;
     long pbeg, pend;
     bool atomic;
@@ -178,16 +181,23 @@ __global__ void __launch_bounds__(256, 2) wgrad_kernel(const WgradParams p)
     const int co_tile = bid % p.n_co_tiles;
     const int rest = bid / p.n_co_tiles;
     const int ci_tile = rest % p.n_ci_tiles;
-    const int tap = rest / p.n_ci_tiles;
+    const int tap_tile = rest / p.n_ci_tiles;
+    const int tap = p.pair_taps ? 2 * tap_tile : tap_tile;          // first (or only) tap of this tile
     const int ky = tap / p.KW, kx = tap - ky * p.KW;
     const long tap_off = (long)(ky - p.pad) * p.x_row_stride + (long)(kx - p.pad) * p.x_px_stride;
+    const int ky2 = (tap + 1) / p.KW, kx2 = (tap + 1) - ky2 * p.KW;   // pair mode: the tap of tile columns 64..127
+    const long tap_off2 = (long)(ky2 - p.pad) * p.x_row_stride + (long)(kx2 - p.pad) * p.x_px_stride;
+    const bool tap2_ok = tap + 1 < p.ntaps;
     const int co0 = co_tile * WG_T, ci0 = ci_tile * WG_T;
+    // columns of this tile that exist in dw[co][tap][ci]
+    const int col_lim = p.pair_taps ? (tap2_ok ? 2 * p.Cin : p.Cin) : p.Cin - ci0;
 
 
     // ---- LDS-DMA sources.  A wave-instruction covers 4 pixel rows x 256 B.  Slot (row, c') holds
     // data chunk c = c' ^ ((row&3)<<2): the transposing reads of one 32-lane half then touch 16
     // distinct 16-B slots of the 256-B bank row (conflict-free).
     int row_of[4], a_coff[4], b_coff[4];
+    bool b_second[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int pos = (i * 4 + wave) * 64 + lane;
@@ -196,6 +206,11 @@ __global__ void __launch_bounds__(256, 2) wgrad_kernel(const WgradParams p)
         row_of[i] = row;
         int ca = co0 / 8 + c, cb = ci0 / 8 + c;
         if (ca >= p.Cout_ld / 8) ca = p.Cout_ld / 8 - 1;
+        b_second[i] = false;
+        if (p.pair_taps) {                      // chunks 0..7 -> tap, 8..15 -> tap + 1 (Cin == 64: 8 chunks per tap)
+            b_second[i] = c >= 8;
+            cb = c & 7;
+        }
         if (cb >= p.Cin_ld / 8) cb = p.Cin_ld / 8 - 1;
         a_coff[i] = ca * 8;
         b_coff[i] = cb * 8;
@@ -231,7 +246,7 @@ __global__ void __launch_bounds__(256, 2) wgrad_kernel(const WgradParams p)
             }
             const bool ok = pr < pend;
             const bf16_t *sa = ok ? p.dy + slot * p.dy_px_stride + a_coff[i] : zline;
-            const bf16_t *sx = ok ? p.x + slot * p.x_px_stride + tap_off + b_coff[i] : zline;
+            const bf16_t *sx = (ok && !(b_second[i] && !tap2_ok)) ? p.x + slot * p.x_px_stride + (b_second[i] ? tap_off2 : tap_off) + b_coff[i] : zline;
             GLDS16(sa, sb + (i * 4 + wave) * 1024);
             GLDS16(sx, sb + WG_TILE_BYTES + (i * 4 + wave) * 1024);
         }
@@ -322,7 +337,7 @@ __global__ void __launch_bounds__(256, 2) wgrad_kernel(const WgradParams p)
             for (int it = 0; it < 8; ++it) {
                 const int idx = it * 256 + tid, row = idx >> 5, c4 = (idx & 31) * 4;
                 const int co = co0 + h * 64 + row, ci = ci0 + c4;
-                if (co < p.Cout && ci < p.Cin)   // Cin % 4 == 0: a quad is inside or outside as a whole
+                if (co < p.Cout && c4 < col_lim)   // Cin % 4 == 0: a quad is inside or outside as a whole
                     *reinterpret_cast<float4 *>(p.dw + (long)co * ldw + (long)tap * p.Cin + ci) = *reinterpret_cast<const float4 *>(ot + row * WG_T + c4);
             }
         } else {
@@ -330,7 +345,7 @@ __global__ void __launch_bounds__(256, 2) wgrad_kernel(const WgradParams p)
             for (int it = 0; it < 32; ++it) {
                 const int idx = it * 256 + tid, row = idx >> 7, c = idx & 127;
                 const int co = co0 + h * 64 + row, ci = ci0 + c;
-                if (co < p.Cout && ci < p.Cin) {
+                if (co < p.Cout && c < col_lim) {
                     float *o = p.dw + (long)co * ldw + (long)tap * p.Cin + ci;
                     const float v = ot[row * WG_T + c];
                     if (atomic) atomicAdd(o, v);
@@ -834,12 +849,14 @@ YOLO_API int yolo_wgrad(const yolo_wgrad_desc *d, const void *x, const void *dy,
         p.KH = d->KH; p.KW = d->KW; p.pad = d->pad; p.x_row_stride = d->x_row_stride;
         p.n_ci_tiles = (d->Cin + WG_T - 1) / WG_T;
         p.ntaps = d->KH * d->KW;
+        // Cin == 64 with several taps (the 64 -> 192 3x3 layer): two taps per 128-column tile instead of half-empty tiles
+        p.pair_taps = (d->variant <= 1 && d->Cin == 64 && p.ntaps > 1 && d->x_px_stride >= 64) ? 1 : 0;
         const long steps_total = (d->P + WG_BP - 1) / WG_BP;
         // kernel variant: 256-wide co tiles (8 waves, 3 stages) only on request (d->variant == 2): measured no faster
         // than two co-resident 128 x 128 workgroups on any layer of the model
         const bool big = d->variant == 2 || d->variant == 3;   // 3: + staggered two-phase schedule
         p.n_co_tiles = big ? (d->Cout + W2_TCO - 1) / W2_TCO : (d->Cout + WG_T - 1) / WG_T;
-        const int tiles = p.n_co_tiles * p.n_ci_tiles * p.ntaps;
+        const int tiles = p.n_co_tiles * p.n_ci_tiles * (p.pair_taps ? (p.ntaps + 1) / 2 : p.ntaps);
         dim3 grid;
         if (d->split > 0) {
             // uniform split, 2-D grid (tiles x ranges)
