@@ -131,7 +131,9 @@ typedef struct yolo_igemm_desc {
     int64_t aux_img_stride;
     int32_t aux_row_stride, aux_px_stride, aux_off;
     int32_t pool2;          /* 1: fuse MaxPool2d(2,2) into the epilogue (conv -> LeakyReLU -> pool, models.py:49-55):
-                               Ho/Wo stay the CONV output size, out_* address the pooled map [Ho/2][Wo/2]     */
+                               Ho/Wo stay the CONV output size, out_* address the pooled map [Ho/2][Wo/2];
+                               2: as 1, and the UN-pooled activation is also written, to `aux` with the aux_* strides
+                               (training keeps it for the backward pass)                                       */
     int32_t w_blocked;      /* 1: w is in the panel layout of yolo_pack_fc_weight_blocked (Linear layers)      */
     int32_t tile_order;     /* 0 = heuristic; 1 = channel tiles fastest; 2 = pixel tiles fastest inside an XCD's range   */
     int32_t tile_hint;      /* 0 = let the library pick the tile configuration; 1: 128x128, 2: 256x128

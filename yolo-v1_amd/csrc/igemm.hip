@@ -462,6 +462,28 @@ __global__ void __launch_bounds__(WCO * WPX * 64, 2) igemm_kernel(const IgemmPar
                 pk.w = (unsigned)f32_to_bf16(v[6]) | ((unsigned)f32_to_bf16(v[7]) << 16);
                 *reinterpret_cast<uint4 *>(reinterpret_cast<bf16_t *>(p.out) + ob + co) = pk;
             }
+            if (p.pool == 2) {
+                // pool2 = 2 (training): the un-pooled activation is written as well, through the aux pointer / strides
+                // (table entry 2 = un-pooled address of every tile pixel), so no separate pooling pass reads it back
+                bf16_t *full = const_cast<bf16_t *>(p.aux);
+                for (int lp = tid / CCH; lp < PPX; lp += PX_PER_STEP) {
+                    const int px = pbase + lp;
+                    if (tab[4 * px + 1] < 0) continue;
+                    if (co >= p.Cout) continue;
+                    float v[8];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        const float m = ep[lp * Cfg::EP + cc * 8 + k] + bias8[k];
+                        v[k] = (p.epilogue == YOLO_EPI_BIAS_LRELU && m < 0.0f) ? m * p.slope : m;
+                    }
+                    uint4 pk;
+                    pk.x = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
+                    pk.y = (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
+                    pk.z = (unsigned)f32_to_bf16(v[4]) | ((unsigned)f32_to_bf16(v[5]) << 16);
+                    pk.w = (unsigned)f32_to_bf16(v[6]) | ((unsigned)f32_to_bf16(v[7]) << 16);
+                    *reinterpret_cast<uint4 *>(full + tab[4 * px + 2] + co) = pk;
+                }
+            }
             continue;
         }
 #pragma unroll 2
@@ -635,7 +657,8 @@ YOLO_API int yolo_igemm(const yolo_igemm_desc *d, const void *in, const void *w,
     const int force = d->tile_hint;   // 0 = heuristic; tests / tuning may force a configuration
     p.w_blocked = d->w_blocked;
     p.px_fastest = d->tile_order == 1 ? 0 : (d->tile_order == 2 ? 1 : -1);
-    p.pool = d->pool2 ? 1 : 0;
+    p.pool = d->pool2 == 2 ? 2 : (d->pool2 ? 1 : 0);
+    if (p.pool == 2 && !aux) return fail(YOLO_E_ARG, "yolo_igemm: pool2 = 2 writes the un-pooled activation through aux (pointer + aux_* strides)");
     p.pool_tw = 16;
     if (p.pool && (splits > 1 || d->out_fp32 || (d->Ho & 1) || (d->Wo & 1) || (d->epilogue != YOLO_EPI_BIAS && d->epilogue != YOLO_EPI_BIAS_LRELU)))
         return fail(YOLO_E_UNSUPPORTED, "yolo_igemm: pool2 needs even Ho/Wo, bf16 output, a bias epilogue and no split-K");

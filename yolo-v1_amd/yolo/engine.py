@@ -608,6 +608,19 @@ class Plan:
                     cur = dst
                     skip_pool = fuse or dual
                     continue
+                # training: the same fused pool, with the un-pooled activation written too (pool2 = 2)
+                dual = (train and FUSE_POOL and not fuse and li + 1 < len(self.layers) and self.layers[li + 1].kind == "pool"
+                        and L.Hout % 8 == 0 and L.Wout % 16 == 0 and L.Cout % 8 == 0 and not L.first)
+                if dual:
+                    full, pooled = nxt, ws["acts"][li + 1]
+                    d = self._conv_desc(L, cur, pooled)
+                    d.pool2 = 2
+                    d.aux_img_stride, d.aux_row_stride, d.aux_px_stride, d.aux_off = full.img_stride, full.row_stride, full.px_stride, full.interior_off()
+                    with _timed(f"conv{li}+pool", "igemm", 2.0 * N * L.Hout * L.Wout * L.Cout * L.Cin * L.K * L.K):
+                        igemm_call(d, cur.p, ptr(wf), ptr(b), full.p, pooled.p, st, f"igemm conv{li}")
+                    cur = pooled
+                    skip_pool = True
+                    continue
                 with _timed(f"conv{li}" + ("+pool" if fuse else ""), "igemm", 2.0 * N * L.Hout * L.Wout * L.Cout * L.Cin * L.K * L.K):
                     igemm_call(d, cur.p, ptr(wf), ptr(b), None, nxt.p, st, f"igemm conv{li}")
                 cur = nxt
