@@ -1,0 +1,95 @@
+"""VOC reader / target encoder / augmentation of yolo.dataset on a tiny VOC tree generated on the fly."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+from PIL import Image
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "yolo-v1_amd"))
+
+from yolo.dataset import CombinedVOCDataset, VOCDetectionYOLO, create_voc_datasets, encode_target  # noqa: E402
+
+XML = """<annotation>
+  <folder>VOC2007</folder><filename>{name}.jpg</filename>
+  <size><width>{w}</width><height>{h}</height><depth>3</depth></size>
+  <segmented>0</segmented>
+  {objects}
+</annotation>"""
+OBJ = "<object><name>{cls}</name><pose>Left</pose><truncated>0</truncated><difficult>0</difficult><bndbox><xmin>{x0}</xmin><ymin>{y0}</ymin><xmax>{x1}</xmax><ymax>{y1}</ymax></bndbox></object>"
+
+
+def _make_voc(root, year, samples, sets):
+    d = root / "VOCdevkit" / f"VOC{year}"
+    for sub in ("JPEGImages", "Annotations", "ImageSets/Main"):
+        (d / sub).mkdir(parents=True, exist_ok=True)
+    rng = np.random.default_rng(0)
+    for name, (w, h, objs) in samples.items():
+        Image.fromarray(rng.integers(0, 256, size=(h, w, 3), dtype=np.uint8)).save(d / "JPEGImages" / f"{name}.jpg")
+        (d / "Annotations" / f"{name}.xml").write_text(XML.format(name=name, w=w, h=h, objects="".join(
+            OBJ.format(cls=c, x0=x0, y0=y0, x1=x1, y1=y1) for c, x0, y0, x1, y1 in objs)))
+    for s, names in sets.items():
+        (d / "ImageSets" / "Main" / f"{s}.txt").write_text("\n".join(names) + "\n")
+
+
+@pytest.fixture()
+def voc(tmp_path):
+    samples = {"000001": (500, 375, [("dog", 48, 240, 195, 371), ("person", 8, 12, 352, 498)]),     # 2 objects (a list in the dict)
+               "000002": (320, 480, [("car", 100, 100, 200, 300)]),                                  # 1 object (still a list)
+               "000003": (200, 200, []),                                                             # no object
+               "000004": (400, 300, [("unicorn", 10, 10, 50, 50), ("cat", 0, 0, 400, 300)])}         # unknown class is skipped
+    _make_voc(tmp_path, "2007", samples, {"train": ["000001", "000002"], "val": ["000003", "000004"], "trainval": list(samples), "test": ["000004"]})
+    _make_voc(tmp_path, "2012", {"2012_000001": (500, 333, [("bird", 10, 20, 110, 220)])}, {"train": ["2012_000001"], "val": ["2012_000001"]})
+    return tmp_path
+
+
+def test_eval_samples_and_targets(voc):
+    ds = VOCDetectionYOLO(root=voc, year="2007", image_set="val", augment=True)      # augment is ignored outside "train"
+    assert len(ds) == 2 and not ds.augment and ds.C == 20 and ds.class_to_idx["tvmonitor"] == 19
+    img, tgt = ds[1]
+    assert img.shape == (3, 448, 448) and img.dtype == torch.float32 and tgt.shape == (7, 7, 30)
+    # the whole-image cat: centre cell (3, 3), cell-relative (0.5, 0.5), w = h = 1; the unknown class left no trace
+    assert tgt[..., 4].sum() == 1 and tgt[3, 3, 4] == 1 and tgt[3, 3, 10 + 7] == 1
+    torch.testing.assert_close(tgt[3, 3, :4], torch.tensor([0.5, 0.5, 1.0, 1.0]))
+    img0, tgt0 = ds[0]
+    assert tgt0.abs().sum() == 0                                                      # image without objects
+    # annotation dict has torchvision's shape: "object" is a list even for one object
+    _, ann = VOCDetectionYOLO(root=voc, year="2007", image_set="train", augment=False)._load(1)
+    assert isinstance(ann["annotation"]["object"], list) and ann["annotation"]["size"]["width"] == "320"
+
+
+def test_target_encoding_rule():
+    # two objects in one cell: the first wins; slot 0 only; one-hot class (reference dataset.py:487-532)
+    t = encode_target([[0.5, 0.5, 0.2, 0.2], [0.52, 0.52, 0.4, 0.4], [0.999, 0.0, 0.1, 0.1]], [3, 5, 0])
+    assert t[3, 3, 4] == 1 and t[3, 3, 10 + 3] == 1 and t[3, 3, 10 + 5] == 0 and t[3, 3, 5:10].abs().sum() == 0
+    torch.testing.assert_close(t[3, 3, :4], torch.tensor([0.5, 0.5, 0.2, 0.2]))
+    assert t[0, 6, 4] == 1 and abs(float(t[0, 6, 0]) - (7 * 0.999 - 6)) < 1e-6
+
+
+def test_augmented_training_samples_keep_boxes_consistent(voc):
+    torch.manual_seed(0)
+    ds = VOCDetectionYOLO(root=voc, year="2007", image_set="train", augment=True)
+    assert ds.augment
+    for _ in range(5):
+        img, tgt = ds[0]
+        assert img.shape == (3, 448, 448) and torch.isfinite(img).all()
+        obj = tgt[..., 4] > 0
+        assert 1 <= int(obj.sum()) <= 2
+        assert (tgt[obj][:, :4] >= 0).all() and (tgt[obj][:, :4] <= 1).all() and (tgt[obj][:, 10:].sum(1) == 1).all()
+    a, _ = ds[1]
+    b, _ = ds[1]
+    assert not torch.equal(a, b)                                                      # random crop / colour jitter
+
+
+def test_combined_and_factory(voc):
+    both = create_voc_datasets([("2007", "trainval"), ("2012", "train")], augment=False, root=voc)
+    assert isinstance(both, CombinedVOCDataset) and len(both) == 5 and both.S == 7
+    img, tgt = both[4]                                                                # the VOC2012 bird
+    assert tgt[..., 10 + 2].sum() == 1
+    with pytest.raises(IndexError):
+        both[5]
+    single = create_voc_datasets([("2012", "val")], augment=False, root=voc)
+    assert isinstance(single, VOCDetectionYOLO) and len(single) == 1
+    with pytest.raises(FileNotFoundError):
+        VOCDetectionYOLO(root=voc, year="2012", image_set="test")

@@ -28,7 +28,7 @@ def main():
     ap.add_argument("--synthetic", type=int, default=0)
     ap.add_argument("--output", default="evaluation_results.txt")
     a = ap.parse_args()
-    ds = SyntheticYOLODataset(a.synthetic, seed=2) if a.synthetic else create_voc_datasets()[1]
+    ds = SyntheticYOLODataset(a.synthetic, seed=2) if a.synthetic else create_voc_datasets([("2007", "test")], augment=False)
     loader = DataLoader(ds, batch_size=a.batch_size, shuffle=False, num_workers=4)
     bb = YOLOv1Backbone() if a.backbone == "yolov1" else ResNetBackbone(pretrained=False)
     model = YOLOv1(backbone=bb, num_classes=20)

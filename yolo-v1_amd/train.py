@@ -61,7 +61,8 @@ def main():
     if a.synthetic:
         train_ds, val_ds = SyntheticYOLODataset(a.synthetic, seed=0), SyntheticYOLODataset(max(a.batch_size, a.synthetic // 8), seed=1)
     else:
-        train_ds, val_ds = create_voc_datasets()
+        train_ds = create_voc_datasets([("2007", "trainval"), ("2012", "train")], augment=True)     # the reference's splits (src/train.py:106-122)
+        val_ds = create_voc_datasets([("2012", "val")], augment=False)
     sampler = DistributedSampler(train_ds, num_replicas=world, rank=rank) if world > 1 else None
     train_loader = DataLoader(train_ds, batch_size=a.batch_size, shuffle=sampler is None, sampler=sampler, num_workers=a.num_workers,
                               pin_memory=device == "cuda", drop_last=True)
