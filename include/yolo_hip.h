@@ -341,6 +341,17 @@ int yolo_adam_step_multi(const yolo_adam_tensor *t, int count, float lr, float b
 /* g *= min(1, max_norm / (sqrt(*norm_sq) + 1e-6))  (stand-alone clip_grad_norm_ for other optimizers). */
 int yolo_clip_scale_f32(float *g, long n, const double *norm_sq, float max_norm, yolo_stream_t stream);
 
+/* BatchNorm2d forward in TRAINING mode (batch statistics) + optional residual add + optional ReLU, in place on a
+ * zero-haloed NHWC bf16 conv output z [N][H+2h][W+2h][C] (C % 8 == 0).  The reference's default model trains with a
+ * frozen ResNet-50 backbone whose BatchNorm layers still run in training mode (trainer.py:49): they normalise with
+ * the batch mean / biased variance and update running_mean / running_var (unbiased) with `momentum`, as aten
+ * batch_norm(training=True) does.  acc2c: 2*C doubles, zero on entry and on return (scratch shared by all layers);
+ * scale_shift: 2*C floats of scratch; residual: NHWC bf16 of the same H, W, C (NULL: none).  Forward only. */
+int yolo_batchnorm_train_fwd(void *z_bf16, int N, int H, int W, int C, int halo, const float *gamma, const float *beta,
+                             double eps, double momentum, float *running_mean, float *running_var,
+                             const void *residual_bf16, int residual_halo, int relu, double *acc2c,
+                             float *scale_shift, yolo_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * TP / FP matching of mAPMetric on the device.  Replaces the per-class greedy matching loops of
  * src/yolo/metrics.py:343-442 (AP per class and threshold), :444-491 (overall precision / recall) and :568-651 (size

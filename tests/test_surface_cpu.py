@@ -289,3 +289,23 @@ def test_checkpoint_with_map_metrics_loads_with_weights_only(tmp_path):
     for f in ("a.pth", "b.pth"):
         ck = torch.load(tmp_path / f, map_location="cpu", weights_only=True)
         assert ck["epoch"] == 3 and ck["mAP50"] == 0.5 and type(ck["val_loss"]) is float
+
+
+def test_north_star_functional_spellings():
+    """cellboxes_to_boxes / non_max_suppression / mean_average_precision / YoloLoss: thin wrappers over the reference-named API."""
+    import numpy as np
+    import torch
+    import yolo
+    from yolo.inference import YOLOInference
+    rng = np.random.default_rng(3)
+    pred = torch.from_numpy(rng.uniform(0, 1, size=(2, 7, 7, 30)).astype(np.float32))
+    boxes = yolo.cellboxes_to_boxes(pred, 0.3)
+    inf = YOLOInference(yolo.YOLOv1(), device="cpu")
+    dets = inf.parse_predictions(pred[0], 0.3)
+    assert len(boxes) == 2 and len(boxes[0]) == len(dets) and boxes[0][0][1] == dets[0].confidence
+    kept = yolo.non_max_suppression(boxes[0], 0.4)
+    ref = inf.non_max_suppression(dets, nms_threshold=0.4)
+    assert len(kept) == len(ref) and all(k[1] == d.confidence and int(k[0]) == d.class_id for k, d in zip(kept, ref))
+    tgt = torch.zeros(2, 7, 7, 30)
+    out = yolo.mean_average_precision(pred, tgt)
+    assert "mAP50:95" in out and yolo.YoloLoss is yolo.YOLOLoss

@@ -1,0 +1,137 @@
+// BatchNorm2d in TRAINING mode (batch statistics) on zero-haloed NHWC bf16, forward only, for gfx950.
+// The reference trains its default model with a FROZEN ResNet-50 backbone whose BatchNorm layers nevertheless run in
+// training mode -- train_epoch calls model.train() on the whole model (src/yolo/training/trainer.py:49), so they
+// normalise with the batch statistics and update their running statistics.  Such a layer cannot be
+// folded into the convolution; it becomes three HBM-bound passes over the conv output z:
+//   bn_stats    : per-channel sum and sum of squares over the N*H*W interior pixels (fp32 partials per thread,
+//                 fp64 atomics per workgroup)
+//   bn_finalize : mean, biased variance, scale = gamma / sqrt(var + eps), shift = beta - mean * scale; running_mean /
+//                 running_var (unbiased) updated with `momentum` exactly as aten does; accumulators cleared
+//   bn_apply    : y = [relu]( z * scale + shift [+ residual] ), in place, 16 B per lane
+// Replaces aten batch_norm (training=True) + relu + the residual add of torchvision's Bottleneck
+// (src/yolo/models.py:154-176 via torchvision.models.resnet50).
+#include "common.h"
+
+namespace yolo {
+
+__device__ __forceinline__ void bn_unpack8(const uint4 &v, float f[8])
+{
+    f[0] = __uint_as_float(v.x << 16); f[1] = __uint_as_float(v.x & 0xffff0000u);
+    f[2] = __uint_as_float(v.y << 16); f[3] = __uint_as_float(v.y & 0xffff0000u);
+    f[4] = __uint_as_float(v.z << 16); f[5] = __uint_as_float(v.z & 0xffff0000u);
+    f[6] = __uint_as_float(v.w << 16); f[7] = __uint_as_float(v.w & 0xffff0000u);
+}
+
+// thread = (channel group of 8, pixel lane); grid-stride over the interior pixels
+__global__ void __launch_bounds__(256) bn_stats_kernel(const bf16_t *__restrict__ z, int N, int H, int W, int C, int halo, double *__restrict__ acc)
+{
+    const int C8 = C >> 3;
+    const int gpb = C8 < 256 ? C8 : 256;          // channel groups per workgroup
+    const int ppb = 256 / gpb;                    // pixel lanes per workgroup
+    const int cg = blockIdx.x * gpb + threadIdx.x % gpb, pl = threadIdx.x / gpb;
+    const long P = (long)N * H * W;
+    const int Hp = H + 2 * halo, Wp = W + 2 * halo;
+    float s[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ss[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (cg < C8 && pl < ppb) {
+        for (long p = (long)blockIdx.y * ppb + pl; p < P; p += (long)gridDim.y * ppb) {
+            const int x = (int)(p % W), y = (int)((p / W) % H), n = (int)(p / ((long)W * H));
+            float f[8];
+            bn_unpack8(*reinterpret_cast<const uint4 *>(z + (((long)n * Hp + y + halo) * Wp + x + halo) * C + cg * 8), f);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { s[k] += f[k]; ss[k] += f[k] * f[k]; }
+        }
+    }
+    __shared__ float red[2][256][9];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { red[0][threadIdx.x][k] = s[k]; red[1][threadIdx.x][k] = ss[k]; }
+    __syncthreads();
+    if (pl == 0 && cg < C8) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            double a = 0.0, b = 0.0;
+            for (int r = 0; r < ppb; ++r) { a += red[0][r * gpb + threadIdx.x][k]; b += red[1][r * gpb + threadIdx.x][k]; }
+            atomicAdd(acc + cg * 8 + k, a);
+            atomicAdd(acc + C + cg * 8 + k, b);
+        }
+    }
+}
+
+__global__ void bn_finalize_kernel(double *__restrict__ acc, int C, double count, const float *__restrict__ gamma, const float *__restrict__ beta, double eps,
+                                   double momentum, float *__restrict__ running_mean, float *__restrict__ running_var, float *__restrict__ scale,
+                                   float *__restrict__ shift)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const double mean = acc[c] / count;
+    double var = acc[C + c] / count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const double invstd = 1.0 / sqrt(var + eps);
+    const double sc = (double)gamma[c] * invstd;
+    scale[c] = (float)sc;
+    shift[c] = (float)((double)beta[c] - mean * sc);
+    if (running_mean) {
+        running_mean[c] = (float)((1.0 - momentum) * (double)running_mean[c] + momentum * mean);
+        const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+        running_var[c] = (float)((1.0 - momentum) * (double)running_var[c] + momentum * unbiased);
+    }
+    acc[c] = 0.0;          // ready for the next layer
+    acc[C + c] = 0.0;
+}
+
+__global__ void __launch_bounds__(256) bn_apply_kernel(bf16_t *__restrict__ z, int N, int H, int W, int C, int halo, const float *__restrict__ scale,
+                                                       const float *__restrict__ shift, const bf16_t *__restrict__ residual, int res_halo, int relu)
+{
+    const int C8 = C >> 3;
+    const long total = (long)N * H * W * C8;
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int cg = (int)(idx % C8);
+    const long p = idx / C8;
+    const int x = (int)(p % W), y = (int)((p / W) % H), n = (int)(p / ((long)W * H));
+    const int Hp = H + 2 * halo, Wp = W + 2 * halo;
+    bf16_t *q = z + (((long)n * Hp + y + halo) * Wp + x + halo) * C + cg * 8;
+    float f[8], r[8];
+    bn_unpack8(*reinterpret_cast<const uint4 *>(q), f);
+    if (residual) {
+        const int Hr = H + 2 * res_halo, Wr = W + 2 * res_halo;
+        bn_unpack8(*reinterpret_cast<const uint4 *>(residual + (((long)n * Hr + y + res_halo) * Wr + x + res_halo) * C + cg * 8), r);
+    }
+    unsigned o[4];
+#pragma unroll
+    for (int k = 0; k < 8; k += 2) {
+        float a = f[k] * scale[cg * 8 + k] + shift[cg * 8 + k], b = f[k + 1] * scale[cg * 8 + k + 1] + shift[cg * 8 + k + 1];
+        if (residual) { a += r[k]; b += r[k + 1]; }
+        if (relu) { a = a > 0.0f ? a : 0.0f; b = b > 0.0f ? b : 0.0f; }
+        o[k >> 1] = (unsigned)f32_to_bf16(a) | ((unsigned)f32_to_bf16(b) << 16);
+    }
+    *reinterpret_cast<uint4 *>(q) = uint4{o[0], o[1], o[2], o[3]};
+}
+
+}  // namespace yolo
+
+using namespace yolo;
+
+YOLO_API int yolo_batchnorm_train_fwd(void *z, int N, int H, int W, int C, int halo, const float *gamma, const float *beta, double eps, double momentum,
+                                      float *running_mean, float *running_var, const void *residual, int residual_halo, int relu, double *acc2c,
+                                      float *scale_shift, yolo_stream_t stream)
+{
+    if (!z || !gamma || !beta || !acc2c || !scale_shift || N <= 0 || H <= 0 || W <= 0 || C <= 0 || halo < 0 || residual_halo < 0)
+        return fail(YOLO_E_ARG, "yolo_batchnorm_train_fwd: bad argument");
+    if (C & 7) return fail(YOLO_E_UNSUPPORTED, "yolo_batchnorm_train_fwd: C = %d must be a multiple of 8", C);
+    if ((running_mean == nullptr) != (running_var == nullptr)) return fail(YOLO_E_ARG, "yolo_batchnorm_train_fwd: running_mean and running_var go together");
+    hipStream_t s = STRM(stream);
+    const int C8 = C / 8, gpb = C8 < 256 ? C8 : 256, ppb = 256 / gpb;
+    const long P = (long)N * H * W;
+    long gy = (P + (long)ppb * 64 - 1) / ((long)ppb * 64);     // ~64 pixels per thread
+    if (gy > 2048) gy = 2048;
+    if (gy < 1) gy = 1;
+    hipLaunchKernelGGL(bn_stats_kernel, dim3((C8 + gpb - 1) / gpb, (unsigned)gy), dim3(256), 0, s, (const bf16_t *)z, N, H, W, C, halo, acc2c);
+    if (int rc = check_launch("yolo_batchnorm_train_fwd(stats)")) return rc;
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, s, acc2c, C, (double)P, gamma, beta, eps, momentum, running_mean, running_var, scale_shift,
+                       scale_shift + C);
+    if (int rc = check_launch("yolo_batchnorm_train_fwd(finalize)")) return rc;
+    const long total = P * C8;
+    hipLaunchKernelGGL(bn_apply_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (bf16_t *)z, N, H, W, C, halo, scale_shift, scale_shift + C,
+                       (const bf16_t *)residual, residual_halo, relu);
+    return check_launch("yolo_batchnorm_train_fwd(apply)");
+}

@@ -43,6 +43,7 @@ def main():
     ap.add_argument("--lambda-noobj", type=float, default=0.5)
     ap.add_argument("--save-frequency", type=int, default=10)
     ap.add_argument("--freeze-backbone", action="store_true")
+    ap.add_argument("--no-pretrained", action="store_true", help="random-init ResNet50 (no torchvision / ImageNet weights available)")
     ap.add_argument("--compute-map", action="store_true")
     ap.add_argument("--checkpoint-dir", default="checkpoints")
     ap.add_argument("--resume", default=None)
@@ -68,7 +69,7 @@ def main():
                               pin_memory=device == "cuda", drop_last=True)
     val_loader = DataLoader(val_ds, batch_size=a.batch_size, shuffle=False, num_workers=a.num_workers, pin_memory=device == "cuda")
 
-    backbone = YOLOv1Backbone() if a.backbone == "yolov1" else ResNetBackbone(pretrained=True, freeze=a.freeze_backbone)
+    backbone = YOLOv1Backbone() if a.backbone == "yolov1" else ResNetBackbone(pretrained=not a.no_pretrained, freeze=a.freeze_backbone)
     model = YOLOv1(backbone=backbone, num_classes=20, S=7, B=2).to(device)
     if world > 1:
         broadcast_parameters(model)

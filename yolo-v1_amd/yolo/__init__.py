@@ -9,6 +9,7 @@ from .schemas import BoundingBox, Detection
 
 # north_star spellings as aliases of the reference's names
 YoloLoss = YOLOLoss
+from .compat import cellboxes_to_boxes, mean_average_precision, non_max_suppression  # noqa: E402,F401
 
 __all__ = [
     "Backbone",

@@ -1061,11 +1061,15 @@ class ResNetPlan:
     """Inference executor for ``yolo.resnet.resnet50_trunk`` on the same kernels: every conv+BN(+ReLU) is
     one yolo_igemm (BN folded into the bf16 weights and an fp32 bias at pack time), the residual add + ReLU
     of a bottleneck is the epilogue of its last 1x1 conv (YOLO_EPI_BIAS_ADD_LRELU with slope 0), the stem's
-    MaxPool2d(3,2,1) is yolo_maxpool3s2_fwd.  Training-mode BatchNorm (batch statistics) is not built."""
+    MaxPool2d(3,2,1) is yolo_maxpool3s2_fwd.  ``forward_batch_stats`` runs the same trunk with BatchNorm in training mode
+    (batch statistics: conv with the raw weights, then yolo_batchnorm_train_fwd) for the FROZEN backbone of a training run;
+    the backward pass through the trunk is not built."""
 
     def __init__(self, trunk: nn.Sequential):
         self.trunk = trunk
         self._packed = None
+        self._raw = None
+        self._bn_scratch = None
         self._bufs: dict = {}
 
     # -- BN folding: y = gamma * (conv(x) - mean) / sqrt(var + eps) + beta
@@ -1105,6 +1109,105 @@ class ResNetPlan:
                 if blk.downsample is not None:
                     pack((li, bi, "d"), blk.downsample[0], blk.downsample[1])
         self._packed = (ver, out)
+        return out
+
+    def _pack_raw(self):
+        """bf16 operands of the UN-folded conv weights (batch-statistics mode: BatchNorm cannot be folded)."""
+        ver = tuple(int(p._version) for n, p in self.trunk.named_parameters() if p.dim() == 4)
+        if self._raw is not None and self._raw[0] == ver:
+            return self._raw[1]
+        st = stream()
+        out = {}
+
+        def pack(name, conv, bn, first=False):
+            w = conv.weight.detach().float().contiguous()
+            co, ci, k, _ = w.shape
+            if first:
+                wf = torch.empty((co, 7, 8, 4), dtype=torch.bfloat16, device=w.device)
+                check(lib().yolo_pack_conv_weight(ptr(w), co, 3, 7, 7, 4, 8, ptr(wf), None, st), "pack stem")
+            else:
+                wf = torch.empty((co, k, k, ci), dtype=torch.bfloat16, device=w.device)
+                check(lib().yolo_pack_conv_weight(ptr(w), co, ci, k, k, ci, k, ptr(wf), None, st), "pack")
+            out[name] = (wf, None, conv, bn)
+
+        pack("stem", self.trunk[0], self.trunk[1], first=True)
+        for li in range(4, 8):
+            for bi, blk in enumerate(self.trunk[li]):
+                pack((li, bi, 1), blk.conv1, blk.bn1)
+                pack((li, bi, 2), blk.conv2, blk.bn2)
+                pack((li, bi, 3), blk.conv3, blk.bn3)
+                if blk.downsample is not None:
+                    pack((li, bi, "d"), blk.downsample[0], blk.downsample[1])
+        self._raw = (ver, out)
+        return out
+
+    def _bn_train(self, a: Act, bn: nn.BatchNorm2d, relu: bool, residual: Act | None, dev, st):
+        """BatchNorm with batch statistics (+ residual, + ReLU) in place on the conv output, running statistics updated."""
+        C = a.C
+        if self._bn_scratch is None or self._bn_scratch[0].device != dev:
+            self._bn_scratch = (torch.zeros(2 * 2048, dtype=torch.float64, device=dev), torch.empty(2 * 2048, dtype=torch.float32, device=dev))
+        acc, ss = self._bn_scratch
+        if C > 2048 or bn.weight is None or not bn.track_running_stats:
+            raise NotImplementedError("batch-statistics BatchNorm: affine layers with running statistics and C <= 2048")
+        mom = 0.1 if bn.momentum is None else bn.momentum
+        check(lib().yolo_batchnorm_train_fwd(a.p, a.N, a.H, a.W, C, a.halo, ptr(bn.weight.detach()), ptr(bn.bias.detach()), float(bn.eps), float(mom),
+                                             ptr(bn.running_mean), ptr(bn.running_var), residual.p if residual is not None else None,
+                                             residual.halo if residual is not None else 0, 1 if relu else 0, ptr(acc), ptr(ss), st), "batchnorm_train_fwd")
+        bn.num_batches_tracked += 1
+
+    def _conv_bn_train(self, tag, a_in: Act, packed, N, relu: bool, residual: Act | None, dev, st):
+        wf, _, conv, bn = packed
+        k, s, p = conv.kernel_size[0], conv.stride[0], conv.padding[0]
+        Ho, Wo = (a_in.H + 2 * p - k) // s + 1, (a_in.W + 2 * p - k) // s + 1
+        a_out = self._act(tag, N, Ho, Wo, conv.out_channels, 1, dev)
+        d = IgemmDesc()
+        d.N, d.Ho, d.Wo = N, Ho, Wo
+        d.in_img_stride, d.in_row_stride, d.in_px_stride = a_in.img_stride, a_in.row_stride, a_in.px_stride
+        d.in_off = a_in.interior_off(p)
+        d.stride, d.KH, d.KW, d.tap_len, d.Cout = s, k, k, conv.in_channels, conv.out_channels
+        d.out_img_stride, d.out_row_stride, d.out_px_stride, d.out_off = a_out.img_stride, a_out.row_stride, a_out.px_stride, a_out.interior_off()
+        d.epilogue, d.slope = EPI_NONE, 1.0
+        with _timed(str(tag), "igemm", 2.0 * N * Ho * Wo * conv.out_channels * conv.in_channels * k * k):
+            igemm_call(d, a_in.p, ptr(wf), None, None, a_out.p, st, f"igemm {tag}")
+        self._bn_train(a_out, bn, relu, residual, dev, st)
+        return a_out
+
+    def forward_batch_stats(self, x: torch.Tensor) -> torch.Tensor:
+        """the trunk with its BatchNorm layers in TRAINING mode (batch statistics, running statistics updated) -- the frozen
+        backbone of the reference's default training run (trainer.py:49).  Forward only: no gradient flows into the trunk."""
+        _hip.require_cuda(x)
+        st = stream()
+        pk = self._pack_raw()
+        N, _, H, W = x.shape
+        dev = x.device
+        x = x.detach()
+        if x.dtype != torch.float32 or not x.is_contiguous():
+            x = x.float().contiguous()
+        a = self._act("in", N, H, W, 4, 3, dev)
+        check(lib().yolo_nchw_f32_to_nhwc_bf16(ptr(x), N, 3, H, W, a.p, 4, 3, 3, st), "nchw->nhwc4")
+        wf, _, conv, bn = pk["stem"]
+        Ho, Wo = (H + 6 - 7) // 2 + 1, (W + 6 - 7) // 2 + 1
+        s1 = self._act("stem", N, Ho, Wo, 64, 1, dev)
+        d = IgemmDesc()
+        d.N, d.Ho, d.Wo = N, Ho, Wo
+        d.in_img_stride, d.in_row_stride, d.in_px_stride, d.in_off = a.img_stride, a.row_stride, a.px_stride, 0
+        d.stride, d.KH, d.KW, d.tap_len, d.Cout = 2, 7, 1, 32, 64
+        d.out_img_stride, d.out_row_stride, d.out_px_stride, d.out_off = s1.img_stride, s1.row_stride, s1.px_stride, s1.interior_off()
+        d.epilogue, d.slope = EPI_NONE, 1.0
+        _igemm(lib(), d, a.p, ptr(wf), None, None, s1.p, st, "igemm stem")
+        self._bn_train(s1, bn, True, None, dev, st)
+        Hq, Wq = (Ho - 1) // 2 + 1, (Wo - 1) // 2 + 1
+        cur = self._act("pool", N, Hq, Wq, 64, 1, dev)
+        pd = PoolDesc(N, Ho, Wo, 64, 1, 1)
+        check(lib().yolo_maxpool3s2_fwd(ctypes.byref(pd), s1.p, cur.p, st), "maxpool3s2")
+        for li in range(4, 8):
+            for bi, blk in enumerate(self.trunk[li]):
+                idn = cur if blk.downsample is None else self._conv_bn_train((li, bi, "d"), cur, pk[(li, bi, "d")], N, False, None, dev, st)
+                t = self._conv_bn_train((li, bi, 1), cur, pk[(li, bi, 1)], N, True, None, dev, st)
+                t = self._conv_bn_train((li, bi, 2), t, pk[(li, bi, 2)], N, True, None, dev, st)
+                cur = self._conv_bn_train((li, bi, 3), t, pk[(li, bi, 3)], N, True, idn, dev, st)
+        out = torch.empty((N, cur.C, cur.H, cur.W), dtype=torch.float32, device=dev)
+        check(lib().yolo_nhwc_bf16_to_nchw_f32(cur.p, N, cur.C, cur.H, cur.W, cur.halo, ptr(out), st), "nhwc->nchw")
         return out
 
     def _act(self, key, N, H, W, C, halo, dev):

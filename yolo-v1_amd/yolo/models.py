@@ -79,8 +79,8 @@ class ResNetBackbone(Backbone):
     The reference wraps ``torchvision.models.resnet50``; torchvision is an un-vendored dependency, so the
     trunk is restated in ``yolo.resnet`` with torchvision's module names (``extractor.N...`` state_dict keys
     are the reference's).  ``pretrained=True`` needs the ImageNet weights, i.e. torchvision + a download.
-    Device tensors in eval mode run on the HIP engine (BatchNorm folded, residual add fused); training-mode
-    BatchNorm on the device is not built this round."""
+    Device tensors run on the HIP engine: eval mode with BatchNorm folded and the residual add fused, training mode
+    (frozen backbone) with batch-statistics BatchNorm; a backward pass through the trunk is not built."""
 
     def __init__(self, pretrained: bool = True, freeze: bool = True):
         super().__init__()
@@ -102,11 +102,15 @@ class ResNetBackbone(Backbone):
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         if x.is_cuda:
-            if self.training or (torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())):
-                raise NotImplementedError("ResNetBackbone on the HIP engine is inference-only this round: call .eval() and "
-                                          "run under torch.no_grad() (or freeze the backbone)")
+            if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+                raise NotImplementedError("ResNetBackbone on the HIP engine has no backward pass: freeze it (freeze=True, the "
+                                          "reference's default) or run under torch.no_grad()")
             if self._plan is None:
                 self._plan = engine.ResNetPlan(self.extractor)
+            if self.training:
+                # frozen but in training mode: BatchNorm uses batch statistics and updates its running statistics, exactly what
+                # the reference does (freeze does not put BN in eval; trainer.py:49 calls model.train() on everything)
+                return self._plan.forward_batch_stats(x)
             return self._plan.forward(x)
         return self.extractor(x)
 
