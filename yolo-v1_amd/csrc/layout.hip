@@ -28,6 +28,36 @@ __global__ void nchw_to_nhwc4_kernel(const float *__restrict__ x, int N, int C, 
     *reinterpret_cast<uint2 *>(y + (((long)n * Hp + h + lo) * Wp + w + lo) * 4) = o;
 }
 
+// the 3-channel image with W % 4 == 0: four pixels per thread -- three 16-B loads (one per plane), two 16-B stores
+__global__ void __launch_bounds__(256) nchw3_to_nhwc4_x4_kernel(const float *__restrict__ x, int N, int H, int W, bf16_t *__restrict__ y, int lo, int hi)
+{
+    const int W4 = W >> 2;
+    const long total = (long)N * H * W4;
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int w = (int)(idx % W4) * 4;
+    const int h = (int)((idx / W4) % H);
+    const int n = (int)(idx / ((long)W4 * H));
+    const int Wp = W + lo + hi, Hp = H + lo + hi;
+    const long plane = (long)H * W;
+    const float *src = x + (long)n * 3 * plane + (long)h * W + w;
+    const float4 r = *reinterpret_cast<const float4 *>(src), g = *reinterpret_cast<const float4 *>(src + plane), b = *reinterpret_cast<const float4 *>(src + 2 * plane);
+    uint4 o0, o1;
+    o0.x = (unsigned)f32_to_bf16(r.x) | ((unsigned)f32_to_bf16(g.x) << 16); o0.y = (unsigned)f32_to_bf16(b.x);
+    o0.z = (unsigned)f32_to_bf16(r.y) | ((unsigned)f32_to_bf16(g.y) << 16); o0.w = (unsigned)f32_to_bf16(b.y);
+    o1.x = (unsigned)f32_to_bf16(r.z) | ((unsigned)f32_to_bf16(g.z) << 16); o1.y = (unsigned)f32_to_bf16(b.z);
+    o1.z = (unsigned)f32_to_bf16(r.w) | ((unsigned)f32_to_bf16(g.w) << 16); o1.w = (unsigned)f32_to_bf16(b.w);
+    bf16_t *dst = y + (((long)n * Hp + h + lo) * Wp + w + lo) * 4;       // 8-B aligned (pixel = 8 B); 16-B only if (w + lo) is even
+    if ((reinterpret_cast<uintptr_t>(dst) & 15) == 0) {
+        *reinterpret_cast<uint4 *>(dst) = o0;
+        *reinterpret_cast<uint4 *>(dst + 8) = o1;
+    } else {
+        *reinterpret_cast<uint2 *>(dst) = uint2{o0.x, o0.y};
+        *reinterpret_cast<uint4 *>(dst + 4) = uint4{o0.z, o0.w, o1.x, o1.y};
+        *reinterpret_cast<uint2 *>(dst + 12) = uint2{o1.z, o1.w};
+    }
+}
+
 // general C: 32(c) x 32(w) tile through LDS.  grid = (ceil(W/32), ceil(C/32), N*H)
 __global__ void __launch_bounds__(256) nchw_to_nhwc_tile_kernel(const float *__restrict__ x, int N, int C, int H, int W,
                                                                 bf16_t *__restrict__ y, int Cpad, int lo, int hi)
@@ -420,7 +450,10 @@ YOLO_API int yolo_nchw_f32_to_nhwc_bf16(const float *x, int N, int C, int H, int
 {
     if (!x || !y || N <= 0 || C <= 0 || H <= 0 || W <= 0 || Cpad < C || halo_lo < 0 || halo_hi < 0) return fail(YOLO_E_ARG, "yolo_nchw_f32_to_nhwc_bf16: bad argument");
     if (Cpad == 4 && C <= 4) {
-        hipLaunchKernelGGL(nchw_to_nhwc4_kernel, dim3(nblk((long)N * H * W, 256)), dim3(256), 0, STRM(stream), x, N, C, H, W, (bf16_t *)y, halo_lo, halo_hi);
+        if (C == 3 && (W & 3) == 0 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)y & 15) == 0)
+            hipLaunchKernelGGL(nchw3_to_nhwc4_x4_kernel, dim3(nblk((long)N * H * (W / 4), 256)), dim3(256), 0, STRM(stream), x, N, H, W, (bf16_t *)y, halo_lo, halo_hi);
+        else
+            hipLaunchKernelGGL(nchw_to_nhwc4_kernel, dim3(nblk((long)N * H * W, 256)), dim3(256), 0, STRM(stream), x, N, C, H, W, (bf16_t *)y, halo_lo, halo_hi);
     } else {
         if ((long)N * H > 65535) return fail(YOLO_E_UNSUPPORTED, "yolo_nchw_f32_to_nhwc_bf16: N*H=%ld > 65535", (long)N * H);
         hipLaunchKernelGGL(nchw_to_nhwc_tile_kernel, dim3(nblk(W, 32), nblk(Cpad, 32), N * H), dim3(256), 0, STRM(stream), x, N, C, H, W, (bf16_t *)y, Cpad, halo_lo, halo_hi);
