@@ -311,7 +311,7 @@ def test_wgrad_kernel_variants_agree_bit_for_bit(Cin):
     x.interior().copy_(torch.randn(N, H, W, Cin, device="cuda").to(torch.bfloat16))
     dy.interior().copy_((torch.randn(N, H, W, Cout, device="cuda") * 0.1).to(torch.bfloat16))
     outs = []
-    for variant in (1, 2, 3):
+    for variant in (1, 2, 3, 4):
         dw = torch.full((Cout, 3, 3, Cin), float("nan"), device="cuda")
         db = torch.zeros(Cout, device="cuda")
         wd = WgradDesc(dy.slots, dy.px_stride, x.px_stride, Cout, Cin, 3, 3, 1, x.row_stride, 1, 0, variant)

@@ -356,6 +356,232 @@ __global__ void __launch_bounds__(256, 2) wgrad_kernel(const WgradParams p)
     }
 }
 
+// 8-wave form of the 128 x 128 kernel: a wave owns 32 co x 64 ci (one A fragment, two B fragments per 16-pixel sub-step),
+// four waves per SIMD with two resident workgroups -- more waves to cover the per-step LDS latency and barrier, at 1.5x the
+// fragment reads per MFMA (yolo_wgrad_desc.variant = 4).
+template <bool BIAS>
+__device__ __forceinline__ void wave_step8(const char *sb, const int (&a_rd)[2], const int (&b_rd)[2], f32x16 (&acc)[1][2], float (&bsum)[2])
+{
+    bf16x8 ca, cb[2], na, nb[2];
+    auto load = [&](int ks, bf16x8 &a, bf16x8 (&b)[2]) {
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(sb + a_rd[0] + ks * 4096));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(sb + a_rd[0] + ks * 4096 + 1024));
+        a = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+        if (BIAS) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) bsum[0] += __uint_as_float(((unsigned)(unsigned short)lo[e]) << 16) + __uint_as_float(((unsigned)(unsigned short)hi[e]) << 16);
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const s16x4 l2 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(sb + b_rd[t] + ks * 4096));
+            const s16x4 h2 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(sb + b_rd[t] + ks * 4096 + 1024));
+            b[t] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(l2, h2, 0, 1, 2, 3, 4, 5, 6, 7));
+        }
+    };
+    load(0, ca, cb);
+#pragma unroll
+    for (int ks = 0; ks < WG_BP / 16; ++ks) {
+        if (ks + 1 < WG_BP / 16) load(ks + 1, na, nb);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ca, cb[j], acc[0][j], 0, 0, 0);
+        ca = na; cb[0] = nb[0]; cb[1] = nb[1];
+    }
+}
+
+__global__ void __launch_bounds__(512, 2) wgrad8_kernel(const WgradParams p)
+{
+    // Two SEPARATE LDS objects, one per pipeline stage, and a K loop unrolled by two so that every
+    // access names its stage statically: hipcc then knows the LDS-DMA writes of stage t+1 cannot alias
+    // the transposing reads of stage t and does not drain vmcnt(0) in front of the first ds_read
+    // (with one array and a runtime stage index it serialised load and compute).
+    __shared__ __attribute__((aligned(16))) char bufA[WG_STAGE_BYTES];
+    __shared__ __attribute__((aligned(16))) char bufB[WG_STAGE_BYTES];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wco = wave >> 1, wci = wave & 1;
+
+    const int ntap_tiles = p.pair_taps ? (p.ntaps + 1) / 2 : p.ntaps;
+    const int nwg = p.n_co_tiles * p.n_ci_tiles * ntap_tiles;
+    int bid;
+    long pbeg, pend;
+    bool atomic;
+    wgrad_map(p, nwg, bid, pbeg, pend, atomic);
+    if (pbeg >= pend) return;   // empty range of a rounded-up split (the whole workgroup leaves)
+    // co-tile fastest, then ci-tile, then tap: neighbours share the x tile of one tap
+    const int co_tile = bid % p.n_co_tiles;
+    const int rest = bid / p.n_co_tiles;
+    const int ci_tile = rest % p.n_ci_tiles;
+    const int tap_tile = rest / p.n_ci_tiles;
+    const int tap = p.pair_taps ? 2 * tap_tile : tap_tile;          // first (or only) tap of this tile
+    const int ky = tap / p.KW, kx = tap - ky * p.KW;
+    const long tap_off = (long)(ky - p.pad) * p.x_row_stride + (long)(kx - p.pad) * p.x_px_stride;
+    const int ky2 = (tap + 1) / p.KW, kx2 = (tap + 1) - ky2 * p.KW;   // pair mode: the tap of tile columns 64..127
+    const long tap_off2 = (long)(ky2 - p.pad) * p.x_row_stride + (long)(kx2 - p.pad) * p.x_px_stride;
+    const bool tap2_ok = tap + 1 < p.ntaps;
+    const int co0 = co_tile * WG_T, ci0 = ci_tile * WG_T;
+    // columns of this tile that exist in dw[co][tap][ci]
+    const int col_lim = p.pair_taps ? (tap2_ok ? 2 * p.Cin : p.Cin) : p.Cin - ci0;
+
+
+    // ---- LDS-DMA sources.  A wave-instruction covers 4 pixel rows x 256 B.  Slot (row, c') holds
+    // data chunk c = c' ^ ((row&3)<<2): the transposing reads of one 32-lane half then touch 16
+    // distinct 16-B slots of the 256-B bank row (conflict-free).
+    int row_of[2], a_coff[2], b_coff[2];
+    bool b_second[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int pos = (i * 8 + wave) * 64 + lane;
+        const int row = pos >> 4, cs = pos & 15;
+        const int c = cs ^ ((row & 3) << 2);
+        row_of[i] = row;
+        int ca = co0 / 8 + c, cb = ci0 / 8 + c;
+        if (ca >= p.Cout_ld / 8) ca = p.Cout_ld / 8 - 1;
+        b_second[i] = false;
+        if (p.pair_taps) {                      // chunks 0..7 -> tap, 8..15 -> tap + 1 (Cin == 64: 8 chunks per tap)
+            b_second[i] = c >= 8;
+            cb = c & 7;
+        }
+        if (cb >= p.Cin_ld / 8) cb = p.Cin_ld / 8 - 1;
+        a_coff[i] = ca * 8;
+        b_coff[i] = cb * 8;
+    }
+    const bf16_t *zline = reinterpret_cast<const bf16_t *>(g_zero_line) + (lane & 15) * 8;
+
+    // slot[i]: buffer slot of the lane's i-th pixel row in the NEXT stage to be issued (-1: past the range -> zeros).
+    // With a pixel index the lookups for stage t+1 are issued right behind the LDS-DMA of stage t and have a whole K
+    // step to arrive.
+    // (n0, oy0, ox0) = pixel coordinates of the first row of the NEXT stage to issue, carried in scalars; a lane's rows lie
+    // < 64 pixels further, so their coordinates follow with two multiply-high "small divisions" each -- no index table, no
+    // extra memory instruction (a table cost 7-17 % on the 56x56 / 112x112 layers, whichever way it was read).
+    int n0 = 0, oy0 = 0, ox0 = 0;
+    if (p.gW) {
+        const long row = pbeg / p.gW;
+        ox0 = (int)(pbeg - row * p.gW);
+        n0 = (int)(row / p.gH);
+        oy0 = (int)(row - (long)n0 * p.gH);
+    }
+    auto stage = [&](char *sb, long pb) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const long pr = pb + row_of[i];
+            long slot;
+            if (p.gW) {
+                const unsigned a = (unsigned)(ox0 + row_of[i]);
+                const unsigned qx = __umulhi(a, p.mW);
+                const unsigned b = (unsigned)oy0 + qx;
+                const unsigned qy = __umulhi(b, p.mH);
+                slot = (long)(n0 + (int)qy) * p.g_img + (int)(b - qy * p.gH) * p.g_row + (int)(a - qx * p.gW) * p.g_px + p.g_off;
+            } else {
+                slot = pr;
+            }
+            const bool ok = pr < pend;
+            const bf16_t *sa = ok ? p.dy + slot * p.dy_px_stride + a_coff[i] : zline;
+            const bf16_t *sx = (ok && !(b_second[i] && !tap2_ok)) ? p.x + slot * p.x_px_stride + (b_second[i] ? tap_off2 : tap_off) + b_coff[i] : zline;
+            GLDS16(sa, sb + (i * 8 + wave) * 1024);
+            GLDS16(sx, sb + WG_TILE_BYTES + (i * 8 + wave) * 1024);
+        }
+        if (p.gW) {   // advance the scalar coordinates by one stage (64 pixels)
+            const unsigned a = (unsigned)(ox0 + WG_BP);
+            const unsigned qx = __umulhi(a, p.mW);
+            const unsigned b = (unsigned)oy0 + qx;
+            const unsigned qy = __umulhi(b, p.mH);
+            ox0 = (int)(a - qx * p.gW);
+            oy0 = (int)(b - qy * p.gH);
+            n0 += (int)qy;
+        }
+    };
+
+    // ---- transposing fragment reads (see header): group g = lane>>4, q = (lane>>2)&3, pp = lane&3
+    const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
+    int a_rd[2], b_rd[2];     // a_rd[1] unused: a wave owns 32 output channels here
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int row = (g >> 1) * 8 + q;
+        const int ca = (wco * 32 + (g & 1) * 16 + 4 * pp) >> 3;
+        const int cb = (wci * 64 + t * 32 + (g & 1) * 16 + 4 * pp) >> 3;
+        a_rd[t] = row * 256 + ((ca ^ ((row & 3) << 2)) << 4) + (pp & 1) * 8;
+        b_rd[t] = WG_TILE_BYTES + row * 256 + ((cb ^ ((row & 3) << 2)) << 4) + (pp & 1) * 8;
+    }
+
+    f32x16 acc[1][2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[0][j][r] = 0.0f;
+
+    // bias gradient rides along: the dy fragments of the (tap 0, ci-tile 0) workgroups cover every
+    // (pixel, co) exactly once over the grid, so summing them costs no extra HBM pass
+    const bool do_bias = p.db != nullptr && tap == 0 && ci_tile == 0 && wci == 0;
+    float bsum[2] = {0.0f, 0.0f};
+
+    auto run = [&](auto bias_tag) {
+        constexpr bool BIAS = decltype(bias_tag)::value;
+        stage(bufA, pbeg);
+        for (long pb = pbeg; pb < pend; pb += 2 * WG_BP) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();  // stage A landed for every wave; stage B is free
+            if (pb + WG_BP < pend) stage(bufB, pb + WG_BP);
+            wave_step8<BIAS>(bufA, a_rd, b_rd, acc, bsum);
+            if (pb + WG_BP >= pend) break;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (pb + 2 * WG_BP < pend) stage(bufA, pb + 2 * WG_BP);
+            wave_step8<BIAS>(bufB, a_rd, b_rd, acc, bsum);
+        }
+    };
+    if (do_bias) run(std::true_type{});
+    else run(std::false_type{});
+
+    if (do_bias) {
+#pragma unroll
+        for (int t = 0; t < 1; ++t) {
+            const float tot = bsum[t] + __shfl_xor(bsum[t], 32, 64);  // the two k-halves of each co row
+            const int co = co0 + wco * 32 + (lane & 31);
+            if (lane < 32 && co < p.Cout) atomicAdd(p.db + co, tot);
+        }
+    }
+
+    // ---- output through LDS, one half of the co rows at a time ([64 co][128 ci] fp32 = stage A): the accumulator layout
+    // (row = (reg&3) + 8*(reg>>2) + 4*(lane>>5), col = lane&31) would give 4-B stores / atomics in 128-B pieces; from LDS
+    // a wave-instruction covers 1 KB of one dw row as 16-B stores, or 256 contiguous bytes per atomic instruction.
+    const long ldw = (long)p.ntaps * p.Cin;
+    float *ot = reinterpret_cast<float *>(bufA);
+    const bool vec_ok = !atomic && (p.Cin & 3) == 0 && ((uintptr_t)p.dw & 15) == 0;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        __syncthreads();   // (first pass: every wave is done reading the stage buffers)
+        if ((wco >> 1) == h) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    ot[((wco & 1) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * WG_T + wci * 64 + j * 32 + (lane & 31)] = acc[0][j][r];
+        }
+        __syncthreads();
+        if (vec_ok) {
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int idx = it * 512 + tid, row = idx >> 5, c4 = (idx & 31) * 4;
+                const int co = co0 + h * 64 + row, ci = ci0 + c4;
+                if (co < p.Cout && c4 < col_lim)   // Cin % 4 == 0: a quad is inside or outside as a whole
+                    *reinterpret_cast<float4 *>(p.dw + (long)co * ldw + (long)tap * p.Cin + ci) = *reinterpret_cast<const float4 *>(ot + row * WG_T + c4);
+            }
+        } else {
+#pragma unroll 4
+            for (int it = 0; it < 16; ++it) {
+                const int idx = it * 512 + tid, row = idx >> 7, c = idx & 127;
+                const int co = co0 + h * 64 + row, ci = ci0 + c;
+                if (co < p.Cout && c < col_lim) {
+                    float *o = p.dw + (long)co * ldw + (long)tap * p.Cin + ci;
+                    const float v = ot[row * WG_T + c];
+                    if (atomic) atomicAdd(o, v);
+                    else *o = v;
+                }
+            }
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------
 // 256 co x 128 ci variant, 8 waves (4 x 2, the same 64 x 64 wave tile), THREE 48-KB stages.
 // The 128 x 128 kernel above keeps at most one 32-KB stage per workgroup in flight (two workgroups per
@@ -850,7 +1076,7 @@ YOLO_API int yolo_wgrad(const yolo_wgrad_desc *d, const void *x, const void *dy,
         p.n_ci_tiles = (d->Cin + WG_T - 1) / WG_T;
         p.ntaps = d->KH * d->KW;
         // Cin == 64 with several taps (the 64 -> 192 3x3 layer): two taps per 128-column tile instead of half-empty tiles
-        p.pair_taps = (d->variant <= 1 && d->Cin == 64 && p.ntaps > 1 && d->x_px_stride >= 64) ? 1 : 0;
+        p.pair_taps = ((d->variant <= 1 || d->variant == 4) && d->Cin == 64 && p.ntaps > 1 && d->x_px_stride >= 64) ? 1 : 0;
         const long steps_total = (d->P + WG_BP - 1) / WG_BP;
         // kernel variant: 256-wide co tiles (8 waves, 3 stages) only on request (d->variant == 2): measured no faster
         // than two co-resident 128 x 128 workgroups on any layer of the model
@@ -907,6 +1133,8 @@ YOLO_API int yolo_wgrad(const yolo_wgrad_desc *d, const void *x, const void *dy,
             }
             if (d->variant == 3) hipLaunchKernelGGL(wgrad256_kernel<true>, grid, dim3(512), 3 * W2_STAGE, s, p);
             else hipLaunchKernelGGL(wgrad256_kernel<false>, grid, dim3(512), 3 * W2_STAGE, s, p);
+        } else if (d->variant == 4) {
+            hipLaunchKernelGGL(wgrad8_kernel, grid, dim3(512), 0, s, p);
         } else {
             hipLaunchKernelGGL(wgrad_kernel, grid, dim3(256), 0, s, p);
         }
