@@ -24,7 +24,11 @@ _CLIP = 10.0
 
 
 def train_epoch(model, dataloader, criterion, optimizer, device, epoch: int, writer=None, scaler=None) -> dict[str, float]:
-    """One pass over ``dataloader``; returns the mean of each loss component."""
+    """One pass over ``dataloader``; returns the mean of each loss component.
+
+    ``scaler`` (the reference's fp16 autocast + GradScaler branch, trainer.py:69-83) is accepted and not used: on a ROCm
+    device the engine already computes in bf16 with fp32 accumulation and fp32 master weights, which needs no loss scaling;
+    on the CPU the stock fp32 path runs."""
     model.train()
     sums = dict.fromkeys(_PARTS, 0.0)
     n = 0
