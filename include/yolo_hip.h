@@ -262,6 +262,14 @@ int yolo_conv_stem7_fwd(const void *x_nhwc4_bf16, const void *w_packed_bf16, con
 int yolo_wgrad_stem7(const void *x_nhwc4_bf16, const void *dy_bf16, int N, int Ho, int Wo, long x_img_stride,
                      int x_row_stride, long dy_img_stride, int dy_row_stride, int dy_off, float *dw_oihw,
                      float *db, float *scratch, long scratch_elems, yolo_stream_t stream);
+/* The same with the backward of the MaxPool2d(2,2) + LeakyReLU that follow the stem fused in: y_full = the stem's
+ * un-pooled activation (64 channels), dpool = gradient of the pooled map [Ho/2][Wo/2]; the gradient tile
+ * (arg-max of every window gets dpool * LeakyReLU', the rest 0 -- what yolo_maxpool2_bwd_lrelu writes) is rebuilt in
+ * registers per tile, so that 411 MB gradient buffer (batch 64) is neither written nor read.  Same results bit for bit. */
+int yolo_wgrad_stem7_pooled(const void *x_nhwc4_bf16, const void *y_full_bf16, int N, int Ho, int Wo, long x_img_stride,
+                            int x_row_stride, long y_img_stride, int y_row_stride, int y_off, const void *dpool_bf16,
+                            long dp_img_stride, int dp_row_stride, int dp_off, float slope, float *dw_oihw, float *db,
+                            float *scratch, long scratch_elems, yolo_stream_t stream);
 /* Whole-model forms of the two calls above: every conv layer of the model in ONE launch (LDS-tiled,
  * all HBM accesses in runs of >= 128 B).  Layers need Cout % 64 == 0 (unpack: % 4), Cin % 64 == 0,
  * KH*KW <= 9 and no padding (Cinp = Cin, KWp = KW); either output of a pack item may be NULL. */

@@ -110,8 +110,10 @@ def test_every_layer_teacher_forced(model):
     from yolo import YOLOLoss
     N = 2
     m = model.cuda().eval()
+    from yolo import engine
     plan = m.hip_plan()
     plan.debug_keep = True
+    engine.STEM_POOL_BWD_FUSED = False        # keep the first pool's gradient buffer so that it can be inspected
     try:
         m.zero_grad()
         x = torch.from_numpy(synth.synth_images(N, 3)).cuda()
@@ -120,7 +122,19 @@ def test_every_layer_teacher_forced(model):
         loss.backward()
         torch.cuda.synchronize()
         ws, fc_saved = plan.last
+        unfused = [m.backbone.features[0].weight.grad.clone(), m.backbone.features[0].bias.grad.clone()]
+        # the same pass with the pool backward fused into the stem's weight-gradient kernel: identical bits
+        engine.STEM_POOL_BWD_FUSED = True
+        plan.debug_keep = False
+        m.zero_grad()
+        loss2, _ = YOLOLoss()(m(x), t)
+        loss2.backward()
+        fused = [m.backbone.features[0].weight.grad, m.backbone.features[0].bias.grad]
+        # (dZ of the stem is rebuilt identically; upstream gradients differ run to run only by fp32-atomic order in the
+        #  FC / conv weight gradients, which do not feed the data-gradient chain)
+        assert torch.equal(fused[0], unfused[0]) and torch.equal(fused[1], unfused[1])
     finally:
+        engine.STEM_POOL_BWD_FUSED = True
         plan.debug_keep = False
         plan.last = None
 

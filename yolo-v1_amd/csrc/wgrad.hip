@@ -845,8 +845,15 @@ struct StemWgradParams {
     int N, tiles_x, tiles_y, ntiles;
     long x_img_stride, dy_img_stride;
     int x_row_stride, dy_row_stride, dy_off;
+    // POOLED: `dy` is the layer's un-pooled ACTIVATION and dpool the gradient of the 2x2-pooled map; the gradient tile is
+    // rebuilt on the fly (arg-max of each window gets dpool * LeakyReLU'), exactly as yolo_maxpool2_bwd_lrelu would write it
+    const bf16_t *dpool;
+    long dp_img_stride;
+    int dp_row_stride, dp_off;
+    float slope;
 };
 
+template <bool POOLED>
 __global__ void __launch_bounds__(256, 3) stem_wgrad_kernel(const StemWgradParams p)
 {
     __shared__ __attribute__((aligned(16))) char bufA[ST_STAGE];
@@ -875,10 +882,60 @@ __global__ void __launch_bounds__(256, 3) stem_wgrad_kernel(const StemWgradParam
         const int ty = r % p.tiles_y, n = r / p.tiles_y;
         const bf16_t *dyb = p.dy + (long)n * p.dy_img_stride + (long)(ty * ST_TH) * p.dy_row_stride + tx * ST_TW * 64 + p.dy_off;
         const bf16_t *xb = p.x + (long)n * p.x_img_stride + (long)(ty * ST_TH * 2) * p.x_row_stride + tx * ST_TW * 2 * 4;
+        if (!POOLED) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) GLDS16(dyb + dy_off[i], sb + (i * 4 + wave) * 1024);
+            for (int i = 0; i < 4; ++i) GLDS16(dyb + dy_off[i], sb + (i * 4 + wave) * 1024);
+        }
         GLDS16(xb + x_off[0], sb + ST_DY_BYTES + wave * 1024);
         if (wave < 3) GLDS16(xb + x_off[1], sb + ST_DY_BYTES + (4 + wave) * 1024);
+    };
+    // POOLED: thread = (2x2 window w of the 8x16 tile, 8-channel chunk c): registers hold the window's four activation
+    // vectors and the pooled gradient of the tile fetched one iteration ahead
+    const int pw = tid >> 3, pc = tid & 7, pwy = pw >> 3, pwx = pw & 7;
+    uint4 ry[4], rg;
+    auto load_regs = [&](int tile) {
+        const int tx = tile % p.tiles_x, r = tile / p.tiles_x;
+        const int ty = r % p.tiles_y, n = r / p.tiles_y;
+        const bf16_t *yb = p.dy + (long)n * p.dy_img_stride + (long)(ty * ST_TH + 2 * pwy) * p.dy_row_stride + (tx * ST_TW + 2 * pwx) * 64 + p.dy_off + pc * 8;
+        ry[0] = *reinterpret_cast<const uint4 *>(yb);
+        ry[1] = *reinterpret_cast<const uint4 *>(yb + 64);
+        ry[2] = *reinterpret_cast<const uint4 *>(yb + p.dy_row_stride);
+        ry[3] = *reinterpret_cast<const uint4 *>(yb + p.dy_row_stride + 64);
+        rg = *reinterpret_cast<const uint4 *>(p.dpool + (long)n * p.dp_img_stride + (long)(ty * (ST_TH / 2) + pwy) * p.dp_row_stride + (tx * (ST_TW / 2) + pwx) * 64 +
+                                              p.dp_off + pc * 8);
+    };
+    auto build = [&](char *sb) {
+        const unsigned yv[4][4] = {{ry[0].x, ry[0].y, ry[0].z, ry[0].w}, {ry[1].x, ry[1].y, ry[1].z, ry[1].w}, {ry[2].x, ry[2].y, ry[2].z, ry[2].w},
+                                   {ry[3].x, ry[3].y, ry[3].z, ry[3].w}};
+        const unsigned gv[4] = {rg.x, rg.y, rg.z, rg.w};
+        unsigned o[4][4];
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {           // the two bf16 of a dword
+                float v[4], gg;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[k] = hf ? __uint_as_float(yv[k][d] & 0xffff0000u) : __uint_as_float(yv[k][d] << 16);
+                gg = hf ? __uint_as_float(gv[d] & 0xffff0000u) : __uint_as_float(gv[d] << 16);
+                int am = 0;
+                float m = v[0];
+                if (v[1] > m) { m = v[1]; am = 1; }    // first maximum in (0,0),(0,1),(1,0),(1,1) order, like pool.hip
+                if (v[2] > m) { m = v[2]; am = 2; }
+                if (v[3] > m) { m = v[3]; am = 3; }
+                const unsigned bits = (unsigned)f32_to_bf16(gg * (m > 0.0f ? 1.0f : p.slope));
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const unsigned w16 = am == k ? bits : 0u;
+                    o[k][d] = hf ? (o[k][d] | (w16 << 16)) : w16;
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int px = (2 * pwy + (k >> 1)) * ST_TW + 2 * pwx + (k & 1);
+            const int cs = pc ^ ((((px >> 1) & 1) << 1) | (((px >> 3) & 1) << 2));
+            *reinterpret_cast<uint4 *>(sb + px * 128 + (cs << 4)) = uint4{o[k][0], o[k][1], o[k][2], o[k][3]};
+        }
     };
 
     // ---- fragment addresses: group g = lane>>4 (pixel sub-block of 8), q = (lane>>2)&3 (row), pp = lane&3 (column quad)
@@ -922,17 +979,28 @@ __global__ void __launch_bounds__(256, 3) stem_wgrad_kernel(const StemWgradParam
 
     const int G = gridDim.x;
     int tile = blockIdx.x;
-    if (tile < p.ntiles) stage(bufA, tile);
+    if (tile < p.ntiles) {
+        stage(bufA, tile);
+        if (POOLED) load_regs(tile);
+    }
     while (tile < p.ntiles) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (POOLED) build(bufA);
         __syncthreads();
-        if (tile + G < p.ntiles) stage(bufB, tile + G);
+        if (tile + G < p.ntiles) {
+            stage(bufB, tile + G);
+            if (POOLED) load_regs(tile + G);
+        }
         compute(bufA);
         tile += G;
         if (tile >= p.ntiles) break;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (POOLED) build(bufB);
         __syncthreads();
-        if (tile + G < p.ntiles) stage(bufA, tile + G);
+        if (tile + G < p.ntiles) {
+            stage(bufA, tile + G);
+            if (POOLED) load_regs(tile + G);
+        }
         compute(bufB);
         tile += G;
     }
@@ -1022,8 +1090,30 @@ __global__ void __launch_bounds__(256) colsum_kernel(const bf16_t *__restrict__ 
 
 using namespace yolo;
 
+static int wgrad_stem7_impl(const void *x_nhwc4, const void *dy, int N, int Ho, int Wo, long x_img_stride, int x_row_stride, long dy_img_stride, int dy_row_stride,
+                            int dy_off, const void *dpool, long dp_img_stride, int dp_row_stride, int dp_off, float slope, float *dw_oihw, float *db, float *scratch,
+                            long scratch_elems, yolo_stream_t stream);
+
 YOLO_API int yolo_wgrad_stem7(const void *x_nhwc4, const void *dy, int N, int Ho, int Wo, long x_img_stride, int x_row_stride, long dy_img_stride,
                               int dy_row_stride, int dy_off, float *dw_oihw, float *db, float *scratch, long scratch_elems, yolo_stream_t stream)
+{
+    return wgrad_stem7_impl(x_nhwc4, dy, N, Ho, Wo, x_img_stride, x_row_stride, dy_img_stride, dy_row_stride, dy_off, nullptr, 0, 0, 0, 1.0f, dw_oihw, db, scratch,
+                            scratch_elems, stream);
+}
+
+YOLO_API int yolo_wgrad_stem7_pooled(const void *x_nhwc4, const void *y_full, int N, int Ho, int Wo, long x_img_stride, int x_row_stride, long y_img_stride,
+                                     int y_row_stride, int y_off, const void *dpool, long dp_img_stride, int dp_row_stride, int dp_off, float slope, float *dw_oihw,
+                                     float *db, float *scratch, long scratch_elems, yolo_stream_t stream)
+{
+    if (!dpool || (dp_row_stride & 7) || (dp_img_stride & 7) || (dp_off & 7) || ((uintptr_t)dpool & 15))
+        return fail(YOLO_E_ARG, "yolo_wgrad_stem7_pooled: dpool must be a 16-B aligned NHWC buffer with strides in multiples of 8 elements");
+    return wgrad_stem7_impl(x_nhwc4, y_full, N, Ho, Wo, x_img_stride, x_row_stride, y_img_stride, y_row_stride, y_off, dpool, dp_img_stride, dp_row_stride, dp_off, slope,
+                            dw_oihw, db, scratch, scratch_elems, stream);
+}
+
+static int wgrad_stem7_impl(const void *x_nhwc4, const void *dy, int N, int Ho, int Wo, long x_img_stride, int x_row_stride, long dy_img_stride, int dy_row_stride,
+                            int dy_off, const void *dpool, long dp_img_stride, int dp_row_stride, int dp_off, float slope, float *dw_oihw, float *db, float *scratch,
+                            long scratch_elems, yolo_stream_t stream)
 {
     if (!x_nhwc4 || !dy || !dw_oihw || !scratch || N <= 0 || Ho <= 0 || Wo <= 0) return fail(YOLO_E_ARG, "yolo_wgrad_stem7: bad argument");
     if ((Ho % ST_TH) || (Wo % ST_TW)) return fail(YOLO_E_UNSUPPORTED, "yolo_wgrad_stem7: output %dx%d is not a multiple of %dx%d (use yolo_im2col_rows + yolo_wgrad)", Ho, Wo, ST_TH, ST_TW);
@@ -1037,10 +1127,12 @@ YOLO_API int yolo_wgrad_stem7(const void *x_nhwc4, const void *dy, int N, int Ho
     p.ntiles = (int)nt;
     p.x_img_stride = x_img_stride; p.dy_img_stride = dy_img_stride;
     p.x_row_stride = x_row_stride; p.dy_row_stride = dy_row_stride; p.dy_off = dy_off;
+    p.dpool = (const bf16_t *)dpool; p.dp_img_stride = dp_img_stride; p.dp_row_stride = dp_row_stride; p.dp_off = dp_off; p.slope = slope;
     long G = std::min<long>(nt, 768);
     G = std::min<long>(G, scratch_elems / ST_PART);
     if (G < 1) return fail(YOLO_E_ARG, "yolo_wgrad_stem7: scratch must hold at least %d floats", ST_PART);
-    hipLaunchKernelGGL(stem_wgrad_kernel, dim3((unsigned)G), dim3(256), 0, STRM(stream), p);
+    if (dpool) hipLaunchKernelGGL(stem_wgrad_kernel<true>, dim3((unsigned)G), dim3(256), 0, STRM(stream), p);
+    else hipLaunchKernelGGL(stem_wgrad_kernel<false>, dim3((unsigned)G), dim3(256), 0, STRM(stream), p);
     if (int rc = check_launch("yolo_wgrad_stem7")) return rc;
     hipLaunchKernelGGL(stem_wgrad_reduce_kernel, dim3((ST_PART + 15) / 16), dim3(256), 0, STRM(stream), (const float *)scratch, (int)G, dw_oihw, db);
     return check_launch("yolo_wgrad_stem7(reduce)");

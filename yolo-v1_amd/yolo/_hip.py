@@ -103,6 +103,8 @@ _SIGS = {
     "yolo_conv_stem7_fwd": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_long, c_int, c_float, c_int, c_void_p, c_long, c_int, c_int, c_void_p, c_long,
                             c_int, c_int, c_void_p],
     "yolo_wgrad_stem7": [c_void_p, c_void_p, c_int, c_int, c_int, c_long, c_int, c_long, c_int, c_int, c_void_p, c_void_p, c_void_p, c_long, c_void_p],
+    "yolo_wgrad_stem7_pooled": [c_void_p, c_void_p, c_int, c_int, c_int, c_long, c_int, c_long, c_int, c_int, c_void_p, c_long, c_int, c_int, c_float, c_void_p,
+                                c_void_p, c_void_p, c_long, c_void_p],
     "yolo_maxpool3s2_fwd": [ctypes.POINTER(PoolDesc), c_void_p, c_void_p, c_void_p],
     "yolo_maxpool2_fwd": [ctypes.POINTER(PoolDesc), c_void_p, c_void_p, c_void_p],
     "yolo_maxpool2_bwd_lrelu": [ctypes.POINTER(PoolDesc), c_void_p, c_void_p, c_float, c_void_p, c_void_p],

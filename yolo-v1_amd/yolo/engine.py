@@ -39,6 +39,7 @@ TIMERS: list | None = None
 TILE_HINT = 0
 IGEMM_LAUNCHES = 0  # yolo_igemm launches so far (bench.py: launches per step of the dominant kernel)
 STEM_KERNEL = True  # 7x7/s2 stem through yolo_conv_stem7_fwd (False: the generic row-segment implicit GEMM; tests compare)
+STEM_POOL_BWD_FUSED = True  # backward of the pool + LeakyReLU behind the stem inside yolo_wgrad_stem7_pooled (False: separate pass)
 STRIDE2_CLASSES = True  # data gradient of a stride-2 3x3 conv as four parity-class convs over the non-zero gradient slots
 FUSE_POOL = True   # inference: fold MaxPool2d(2,2) into the preceding conv's epilogue where the geometry allows
 
@@ -745,6 +746,7 @@ class Plan:
         # packed -> OIHW conversion of finished conv gradients is deferred and done for several layers per
         # launch (yolo_unpack_conv_wgrads_multi); gradients become final (and are announced) at the flush
         pending: list[tuple] = []
+        stem_dpool = None            # pooled gradient handed straight to the stem's weight-gradient kernel (pool backward fused there)
 
         def flush():
             items = [ConvUnpackItem(dwp.data_ptr(), dw.data_ptr(), L.Cout, L.Cin, L.K, L.K) for (i, L, dwp, dw) in pending if self._multi_ok(L)]
@@ -858,6 +860,12 @@ class Plan:
                 Lc = self.layers[lc]
                 assert Lc.kind == "conv" and Lc.lrelu, "MaxPool2d is expected right after conv+LeakyReLU"
                 yfull = ws["acts"][lc]
+                if lc == 0 and Lc.first and STEM_POOL_BWD_FUSED and Lc.Cout == 64 and Lc.Hout % 8 == 0 and Lc.Wout % 16 == 0 and g_act.halo == 1:
+                    # the stem's weight-gradient kernel rebuilds this pool's (+ LeakyReLU's) backward per tile from the
+                    # activation and the pooled gradient: the 224x224x64 gradient buffer is never written or read
+                    stem_dpool = g_act
+                    li -= 1
+                    continue
                 g = self._grad_buf(ws, lc, N, dev)
                 pd = PoolDesc(N, yfull.H, yfull.W, yfull.C, 1, 1)
                 with _timed(f"pool{li}.bwd", "maxpool2_bwd"):
@@ -877,8 +885,15 @@ class Plan:
                         part = torch.empty((768 * 14400,), dtype=torch.float32, device=dev)
                         ws["misc"]["stem_part"] = part
                     with _timed(f"conv{li}.wgrad", "wgrad", 2.0 * N * L.Hout * L.Wout * L.Cout * 147):
-                        check(L_.yolo_wgrad_stem7(xin.p, g.p, N, L.Hout, L.Wout, xin.img_stride, xin.row_stride, g.img_stride, g.row_stride,
-                                                  g.interior_off(), ptr(dw), ptr(db), ptr(part), part.numel(), st), "wgrad_stem7")
+                        if stem_dpool is not None:
+                            yf = ws["acts"][0]
+                            check(L_.yolo_wgrad_stem7_pooled(xin.p, yf.p, N, L.Hout, L.Wout, xin.img_stride, xin.row_stride, yf.img_stride, yf.row_stride,
+                                                             yf.interior_off(), stem_dpool.p, stem_dpool.img_stride, stem_dpool.row_stride,
+                                                             stem_dpool.interior_off(), self.SLOPE if L.lrelu else 1.0, ptr(dw), ptr(db), ptr(part),
+                                                             part.numel(), st), "wgrad_stem7_pooled")
+                        else:
+                            check(L_.yolo_wgrad_stem7(xin.p, g.p, N, L.Hout, L.Wout, xin.img_stride, xin.row_stride, g.img_stride, g.row_stride,
+                                                      g.interior_off(), ptr(dw), ptr(db), ptr(part), part.numel(), st), "wgrad_stem7")
                     grads[li] = (dw, db)
                     flush()
                     self._layer_done(li)
