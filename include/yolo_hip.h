@@ -143,6 +143,10 @@ typedef struct yolo_igemm_desc {
                                (0, 0 = all).  Lets a caller run the bulk of a layer with a large tile in whole
                                rounds of the 256 CUs and the remainder with a small tile in one short round,
                                instead of a last round that keeps a few CUs busy for a full large-tile time */
+    int32_t skew_phases;    /* > 1 (8-wave configurations, launches of more than 256 workgroups): the first-round
+                               workgroups start (slot % skew_phases) * skew_step shader cycles late, so that the CUs
+                               do not all reach their output stores at the same moment (0 = off)                  */
+    int32_t skew_step;
 } yolo_igemm_desc;
 
 #define YOLO_EPI_NONE 0        /* out = acc                                                        */

@@ -425,6 +425,42 @@ def test_pixel_range_launches_tile_the_output_exactly():
     plan._release(key, ws)
 
 
+def test_start_skew_changes_nothing_but_time():
+    """yolo_igemm_desc.skew_phases / skew_step: first-round workgroups of the 8-wave configurations start a few thousand
+    cycles apart -- the output must be bit-identical to the plain launch (more than 256 workgroups, so the skew is live)."""
+    from yolo import engine
+    from yolo._hip import lib, ptr, stream
+    torch.manual_seed(8)
+    conv = nn.Conv2d(64, 256, 3, 1, 1).cuda()
+    plan = engine.Plan.from_modules([conv, nn.LeakyReLU(0.1)], 64, False)
+    x = torch.randn(16, 64, 64, 66, device="cuda")
+    with torch.no_grad():
+        engine.run_plan(plan, x, False)
+    key, ws = plan._workspace(16, x.shape, x.device, False)
+    a_in, a_out = ws["in"], ws["acts"][0]
+    from yolo._hip import check
+    check(lib().yolo_nchw_f32_to_nhwc_bf16(ptr(x), 16, 64, 64, 66, a_in.p, 64, 1, 1, stream()))
+    L = plan.layers[0]
+    wf, _ = plan._pack(0, False)
+    d = plan._conv_desc(L, a_in, a_out)
+
+    def run(pl):
+        a_out.t.zero_()
+        engine._run_plan_igemm(lib(), d, pl, a_in.p, ptr(wf), ptr(L.bias.detach()), None, a_out.p, stream(), "test")
+        return a_out.interior().clone()
+
+    for hint in (11, 12):
+        ref = run((hint, 1))
+        for ph, step in ((3, 4000), (5, 20000)):
+            assert torch.equal(run(("skew", hint, 1, ph, step)), ref), (hint, ph, step)
+    assert d.skew_phases == 0 and d.skew_step == 0
+    d.skew_phases = -1
+    import ctypes
+    assert lib().yolo_igemm(ctypes.byref(d), a_in.p, ptr(wf), ptr(L.bias.detach()), None, a_out.p, stream()) != 0
+    d.skew_phases = 0
+    plan._release(key, ws)
+
+
 def test_fused_pool_epilogue_equals_separate_pool():
     """inference path: conv+LeakyReLU+MaxPool as one launch must equal conv, then pool (bit for bit:
     max and the bf16 rounding commute because rounding is monotone)."""

@@ -44,21 +44,39 @@ for item in synth.YOLOV1_BACKBONE_CFG:
     d.epilogue, d.slope, d.out_fp32, d.split_k = EPI_BIAS_LRELU, 0.1, 0, 1
     fl = 2.0 * N * h * h * co * ci * k * k
     line = f"idx {idx:2d} co {co:4d} ci {ci:4d} k {k} s {s} out {h:3d} M {N*h*h:7d} K {ci*k*k:5d} |"
-    for hint in hints:
+    # warm the clocks up on this problem, then time every configuration in three interleaved rounds and keep the
+    # minimum: the first configuration measured after an idle gap otherwise reads 10-20 % slow
+    def run(hint, reps):
         d.tile_hint = hint % 100
         d.tile_order = hint // 100
+        for _ in range(reps):
+            check(lib().yolo_igemm(ctypes.byref(d), x.p, ptr(w), ptr(b), None, y.p, stream()))
+    ok = []
+    for hint in hints:
         try:
-            for _ in range(2):
-                check(lib().yolo_igemm(ctypes.byref(d), x.p, ptr(w), ptr(b), None, y.p, stream()))
+            run(hint, 3)
+            ok.append(hint)
+        except RuntimeError:
+            pass
+    torch.cuda.synchronize()
+    for _ in range(3):
+        for hint in ok:
+            run(hint, 5)
+    best = {}
+    for _ in range(3):
+        for hint in ok:
+            run(hint, 1)
             e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
             e0.record()
-            for _ in range(5):
-                check(lib().yolo_igemm(ctypes.byref(d), x.p, ptr(w), ptr(b), None, y.p, stream()))
+            run(hint, 5)
             e1.record(); torch.cuda.synchronize()
             ms = e0.elapsed_time(e1) / 5
-            tot[hint] += ms
-            line += f" h{hint}: {ms:6.3f} ms {fl/ms/1e9:6.0f} TF |"
-        except RuntimeError as e:
+            best[hint] = min(ms, best.get(hint, 1e9))
+    for hint in hints:
+        if hint in best:
+            tot[hint] += best[hint]
+            line += f" h{hint}: {best[hint]:6.3f} ms {fl/best[hint]/1e9:6.0f} TF |"
+        else:
             line += f" h{hint}: n/a |"
     print(line)
     del x, y

@@ -61,6 +61,8 @@ struct IgemmParams {
     int n_co_tiles, n_px_tiles;
     long px_begin;          // first output pixel of this launch (pixel-range launches: see yolo_igemm_desc.px_begin)
     int px_fastest;         // tile order inside an XCD's contiguous range: 1 = pixel tiles fastest (one weight panel per XCD)
+    int skew_phases;        // > 1: first-round workgroups start skew_cycles * phase late (see yolo_igemm)
+    long skew_cycles;
 };
 
 #define GLDS16(gptr, lptr) \
@@ -122,6 +124,18 @@ __global__ void __launch_bounds__(WCO * WPX * 64, 2) igemm_kernel(const IgemmPar
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wco = wave / WPX, wpx = wave % WPX;
+
+    // ---- start skew (8-wave configurations: one workgroup per CU).  With equal tiles every CU reaches its prologue
+    // burst and its output stores at the same moment and the memory system serves 256 identical phases at once.
+    // Delaying the first-round workgroups of phase 1.. by a fraction of a tile time keeps the CUs out of step for the
+    // rest of the launch (later workgroups inherit the CU's offset); measured 2-8 % on the multi-round layers.
+    if (NW == 8 && p.skew_phases > 1 && gridDim.x * gridDim.y > 256 && blockIdx.y == 0 && blockIdx.x < 256) {
+        const int ph = (blockIdx.x >> 3) % p.skew_phases;
+        if (ph) {
+            const long t0 = __builtin_amdgcn_s_memtime(), wait = ph * p.skew_cycles;
+            while ((long)__builtin_amdgcn_s_memtime() - t0 < wait) __builtin_amdgcn_s_sleep(16);
+        }
+    }
 
     // ---- XCD-aware tile mapping: blocks b, b+8, b+16.. share an XCD; give each XCD a contiguous
     // range of logical tiles (co-tile fastest) so its private L2 sees one activation tile being
@@ -657,6 +671,9 @@ YOLO_API int yolo_igemm(const yolo_igemm_desc *d, const void *in, const void *w,
     const int force = d->tile_hint;   // 0 = heuristic; tests / tuning may force a configuration
     p.w_blocked = d->w_blocked;
     p.px_fastest = d->tile_order == 1 ? 0 : (d->tile_order == 2 ? 1 : -1);
+    if (d->skew_phases < 0 || d->skew_phases > 64 || d->skew_step < 0 || d->skew_step > (1 << 22)) return fail(YOLO_E_ARG, "yolo_igemm: skew_phases %d / skew_step %d", d->skew_phases, d->skew_step);
+    p.skew_phases = d->skew_phases;
+    p.skew_cycles = d->skew_step;
     p.pool = d->pool2 == 2 ? 2 : (d->pool2 ? 1 : 0);
     if (p.pool == 2 && !aux) return fail(YOLO_E_ARG, "yolo_igemm: pool2 = 2 writes the un-pooled activation through aux (pointer + aux_* strides)");
     p.pool_tw = 16;

@@ -38,6 +38,7 @@ class IgemmDesc(ctypes.Structure):
         ("tile_order", ctypes.c_int32),
         ("tile_hint", ctypes.c_int32),
         ("px_begin", ctypes.c_int64), ("px_end", ctypes.c_int64),
+        ("skew_phases", ctypes.c_int32), ("skew_step", ctypes.c_int32),
     ]
 
 

@@ -107,6 +107,16 @@ def _run_plan_igemm(L_, d: IgemmDesc, plan, inp, w, bias, aux, out, st, what):
         _igemm(L_, d2, inp, w, None, None, ptr(acc), st, what)
         check(L_.yolo_igemm_finish(ctypes.byref(d), ptr(acc), bias, aux, out, st), what + " (finish)")
         return
+    if plan[0] == "skew":
+        # ("skew", hint, order, phases, step): one launch of an 8-wave configuration whose first-round workgroups start
+        # phase * step cycles apart (yolo_igemm_desc.skew_phases)
+        d.tile_hint, d.tile_order, d.skew_phases, d.skew_step = plan[1], plan[2], plan[3], plan[4]
+        d.px_begin, d.px_end = 0, 0
+        try:
+            _igemm(L_, d, inp, w, bias, aux, out, st, what)
+        finally:
+            d.skew_phases, d.skew_step = 0, 0
+        return
     d.tile_hint, d.tile_order = plan[0], plan[1]
     if len(plan) == 2:
         d.px_begin, d.px_end = 0, 0
@@ -176,6 +186,21 @@ def igemm_call(d: IgemmDesc, inp, w, bias, aux, out, st, what: str):
                         t = timed((c, o, cut, tc))
                         if t is not None:
                             times[(c, o, cut, tc)] = t
+        # start-skew plans: the 8-wave configurations run one workgroup per CU, all in the same phase; over several rounds
+        # it pays to start the CUs a fraction of a tile time apart (see igemm.hip)
+        if times and not d.pool2:
+            M = d.N * d.Ho * d.Wo
+            for (c, o) in [pl for pl in sorted(times, key=times.get) if len(pl) == 2 and pl[0] in (11, 12)][:2]:
+                tco, tpx = _TILE[c]
+                tiles = ((d.Cout + tco - 1) // tco) * ((M + tpx - 1) // tpx)
+                if tiles < 400:
+                    continue
+                tile_cycles = times[(c, o)] * 1e-3 / ((tiles + 255) // 256) * 2.1e9
+                for ph, frac in ((3, 0.3), (5, 0.2), (3, 0.2), (5, 0.3)):
+                    pl = ("skew", c, o, ph, int(frac * tile_cycles))
+                    t = timed(pl)
+                    if t is not None:
+                        times[pl] = t
         # split-K plans for few-pixel, deep-K layers (7x7x1024: 200 output tiles of 128x128 for 256 CUs)
         if (times and not d.pool2 and not d.out_fp32 and d.N * d.Ho * d.Wo <= 8192 and d.KH * d.KW * d.tap_len >= 2304 and d.Cout % 8 == 0
                 and d.epilogue in (EPI_NONE, EPI_BIAS, EPI_BIAS_LRELU, EPI_MUL_DLRELU)):
