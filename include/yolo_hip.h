@@ -216,6 +216,10 @@ typedef struct yolo_pool_desc {
 /* MaxPool2d(3, stride 2, pad 1) forward (ResNet stem).  The input must be >= 0 (it follows a ReLU), so
  * the zero halo of the buffer is equivalent to the -inf padding of the operator.  H, W = input size. */
 int yolo_maxpool3s2_fwd(const yolo_pool_desc *d, const void *x_bf16, void *y_bf16, yolo_stream_t stream);
+/* its backward (aten max_pool2d_with_indices_backward): dx[n][h][w][c] = sum of dy over the windows whose arg-max
+ * (first maximum in row-major order, recomputed from x) is (h, w).  d->out_halo = halo of dy, dx_halo = halo of dx. */
+int yolo_maxpool3s2_bwd(const yolo_pool_desc *d, const void *x_bf16, const void *dy_bf16, void *dx_bf16, int dx_halo,
+                        yolo_stream_t stream);
 int yolo_maxpool2_fwd(const yolo_pool_desc *d, const void *x_bf16, void *y_bf16, yolo_stream_t stream);
 int yolo_maxpool2_bwd_lrelu(const yolo_pool_desc *d, const void *yfull_bf16, const void *dpool_bf16,
                             float slope, void *dz_bf16, yolo_stream_t stream);
@@ -363,7 +367,24 @@ int yolo_clip_scale_f32(float *g, long n, const double *norm_sq, float max_norm,
 int yolo_batchnorm_train_fwd(void *z_bf16, int N, int H, int W, int C, int halo, const float *gamma, const float *beta,
                              double eps, double momentum, float *running_mean, float *running_var,
                              const void *residual_bf16, int residual_halo, int relu, double *acc2c,
-                             float *scale_shift, yolo_stream_t stream);
+                             float *scale_shift, void *out_bf16, int out_halo, float *save_mean_invstd,
+                             yolo_stream_t stream);
+/* (out_bf16 != NULL: the result goes to that buffer [N][H+2*out_halo][W+2*out_halo][C] and z is kept -- a trainable
+ *  trunk needs z for the backward pass; save_mean_invstd != NULL: 2*C floats, batch mean then 1/sqrt(var + eps).)
+ *
+ * BatchNorm2d backward (training mode) for a conv -> BN [-> + residual] [-> ReLU] unit of a TRAINABLE ResNet trunk
+ * (the reference's default run: ResNetBackbone(pretrained=True, freeze=False), src/train.py:144; aten
+ * native_batch_norm_backward + threshold_backward).  dy: gradient wrt the unit's output; y: that output (ReLU mask,
+ * NULL when the unit has no ReLU); z: the conv output the forward normalised; mean_invstd: as saved by the forward.
+ *   dy' = dy * [y > 0];  dbeta = sum dy';  dgamma = sum dy' * xhat;  dz = gamma * invstd * (dy' - dbeta/M - xhat * dgamma/M)
+ * dz is written at dz[n*dz_img_stride + y*dz_row_stride + x*dz_px_stride + dz_off + c] (doubled strides put it
+ * zero-stuffed on the input grid of a stride-2 conv, the form yolo_wgrad / the data gradient read); store_masked_dy: dy'
+ * replaces dy in place (the identity branch of a bottleneck receives it).  acc2c: 2*C doubles, zero on entry and on
+ * return; coef3c: 3*C floats of scratch. */
+int yolo_batchnorm_bwd(void *dy_bf16, int dy_halo, const void *y_bf16, int y_halo, const void *z_bf16, int z_halo,
+                       int N, int H, int W, int C, const float *gamma, const float *mean_invstd, void *dz_bf16,
+                       long dz_img_stride, long dz_row_stride, long dz_px_stride, long dz_off, int store_masked_dy,
+                       float *dgamma, float *dbeta, double *acc2c, float *coef3c, yolo_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * TP / FP matching of mAPMetric on the device.  Replaces the per-class greedy matching loops of

@@ -92,7 +92,9 @@ _SIGS = {
     "yolo_decode_gt": [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p],
     "yolo_nms": [c_void_p, c_void_p, c_int, c_int, c_double, c_int, c_void_p, c_void_p, c_void_p],
     "yolo_batchnorm_train_fwd": [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_double, c_double, c_void_p, c_void_p, c_void_p, c_int,
-                                 c_int, c_void_p, c_void_p, c_void_p],
+                                 c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p],
+    "yolo_batchnorm_bwd": [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, ctypes.c_long, ctypes.c_long,
+                           ctypes.c_long, ctypes.c_long, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
     "yolo_map_match": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, ctypes.POINTER(c_double), c_int, c_double, c_double, c_double,
                        c_void_p, c_void_p, c_void_p],
     "yolo_pairwise_iou": [c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p],
@@ -107,6 +109,7 @@ _SIGS = {
     "yolo_wgrad_stem7_pooled": [c_void_p, c_void_p, c_int, c_int, c_int, c_long, c_int, c_long, c_int, c_int, c_void_p, c_long, c_int, c_int, c_float, c_void_p,
                                 c_void_p, c_void_p, c_long, c_void_p],
     "yolo_maxpool3s2_fwd": [ctypes.POINTER(PoolDesc), c_void_p, c_void_p, c_void_p],
+    "yolo_maxpool3s2_bwd": [ctypes.POINTER(PoolDesc), c_void_p, c_void_p, c_void_p, c_int, c_void_p],
     "yolo_maxpool2_fwd": [ctypes.POINTER(PoolDesc), c_void_p, c_void_p, c_void_p],
     "yolo_maxpool2_bwd_lrelu": [ctypes.POINTER(PoolDesc), c_void_p, c_void_p, c_float, c_void_p, c_void_p],
     "yolo_nchw_f32_to_nhwc_bf16": [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p],

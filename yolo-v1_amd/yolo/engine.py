@@ -1181,7 +1181,7 @@ class ResNetPlan:
         self._raw = (ver, out)
         return out
 
-    def _bn_train(self, a: Act, bn: nn.BatchNorm2d, relu: bool, residual: Act | None, dev, st):
+    def _bn_train(self, a: Act, bn: nn.BatchNorm2d, relu: bool, residual: Act | None, dev, st, out: Act | None = None, save: torch.Tensor | None = None):
         """BatchNorm with batch statistics (+ residual, + ReLU) in place on the conv output, running statistics updated."""
         C = a.C
         if self._bn_scratch is None or self._bn_scratch[0].device != dev:
@@ -1192,7 +1192,9 @@ class ResNetPlan:
         mom = 0.1 if bn.momentum is None else bn.momentum
         check(lib().yolo_batchnorm_train_fwd(a.p, a.N, a.H, a.W, C, a.halo, ptr(bn.weight.detach()), ptr(bn.bias.detach()), float(bn.eps), float(mom),
                                              ptr(bn.running_mean), ptr(bn.running_var), residual.p if residual is not None else None,
-                                             residual.halo if residual is not None else 0, 1 if relu else 0, ptr(acc), ptr(ss), st), "batchnorm_train_fwd")
+                                             residual.halo if residual is not None else 0, 1 if relu else 0, ptr(acc), ptr(ss),
+                                             out.p if out is not None else None, out.halo if out is not None else 0,
+                                             ptr(save) if save is not None else None, st), "batchnorm_train_fwd")
         bn.num_batches_tracked += 1
 
     def _conv_bn_train(self, tag, a_in: Act, packed, N, relu: bool, residual: Act | None, dev, st):
