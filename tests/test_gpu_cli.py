@@ -56,3 +56,17 @@ def test_train_resume_evaluate_predict(tmp_path):
     outdir = tmp_path / "pred"
     _run([os.path.join(PKG, "predict.py"), str(img), "--checkpoint", str(ck / "yolo_best.pth"), "--backbone", "yolov1", "--output-dir", str(outdir)], str(tmp_path))
     assert (outdir / "img.jpg").exists()     # the annotated copy (schemas validate every kept box, as the reference's do)
+
+
+def test_default_training_model_resnet50_unfrozen(tmp_path):
+    """the reference's default run: ResNet-50 backbone, NOT frozen (src/train.py:144, freeze_backbone=False), DetectionHead;
+    random initialisation because no ImageNet weights can be downloaded here"""
+    ck = tmp_path / "ck"
+    out = _run([os.path.join(PKG, "train.py"), "--epochs", "1", "--batch-size", "4", "--num-workers", "0", "--synthetic", "8", "--no-pretrained",
+                "--checkpoint-dir", str(ck)], str(tmp_path))
+    assert "done:" in out
+    st = torch.load(ck / "yolo_latest.pth", map_location="cpu", weights_only=True)
+    sd = st["model_state_dict"]
+    assert "backbone.extractor.0.weight" in sd and "backbone.extractor.7.2.bn3.running_var" in sd
+    assert all(torch.isfinite(v).all() for v in sd.values())
+    assert int(sd["backbone.extractor.1.num_batches_tracked"]) == 2          # two optimizer steps updated the BatchNorm statistics

@@ -1,0 +1,200 @@
+"""Trainable ResNet trunk on the HIP engine (the reference's default run: ResNetBackbone(pretrained=True, freeze=False),
+src/train.py:144; SURVEY 8a rows a4 x a12).  The building blocks are checked against stock torch on the CPU
+(BatchNorm backward with and without the ReLU mask, MaxPool2d(3,2,1) backward), and the whole backward pass block by
+block with teacher forcing: every bottleneck gets the GPU's own block input and incoming gradient, so bf16 noise does not
+compound through 16 blocks of batch-statistics BatchNorm (see test_frozen_resnet_backbone_in_training_mode)."""
+import copy
+import ctypes
+
+import pytest
+import torch
+import torch.nn as nn
+
+pytestmark = pytest.mark.gpu
+
+
+def _bf(x):
+    return x.to(torch.bfloat16).to(torch.float32)
+
+
+def _rel(a, b):
+    a, b = a.detach().float().cpu(), b.detach().float().cpu()
+    return ((a - b).norm() / (b.norm() + 1e-20)).item()
+
+
+@pytest.mark.parametrize("relu,stride", [(True, 1), (False, 1), (True, 2)])
+def test_batchnorm_backward_matches_autograd(relu, stride):
+    from yolo import engine
+    from yolo._hip import lib, check, ptr, stream
+    torch.manual_seed(0)
+    N, H, W, C = 4, 10, 12, 64
+    z = _bf(torch.randn(N, C, H, W) * 1.5 + 0.3)
+    dy = _bf(torch.randn(N, C, H, W))
+    gamma, beta = torch.rand(C) + 0.5, torch.randn(C)
+    zc = z.clone().requires_grad_(True)
+    gc, bc = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    yc = torch.nn.functional.batch_norm(zc, None, None, gc, bc, True, 0.1, 1e-5)
+    if relu:
+        yc = torch.relu(yc)
+    yc.backward(dy)
+
+    dev = torch.device("cuda")
+    st = stream()
+    za, ya, ga = engine.Act(N, H, W, C, 1, dev), engine.Act(N, H, W, C, 1, dev), engine.Act(N, H, W, C, 1, dev)
+    za.interior().copy_(z.permute(0, 2, 3, 1).to(torch.bfloat16))
+    ga.interior().copy_(dy.permute(0, 2, 3, 1).to(torch.bfloat16))
+    acc = torch.zeros(2 * C, dtype=torch.float64, device=dev)
+    ss = torch.empty(2 * C, dtype=torch.float32, device=dev)
+    save = torch.empty(2 * C, dtype=torch.float32, device=dev)
+    rm, rv = torch.zeros(C, device=dev), torch.ones(C, device=dev)
+    g_d, b_d = gamma.to(dev), beta.to(dev)
+    check(lib().yolo_batchnorm_train_fwd(za.p, N, H, W, C, 1, ptr(g_d), ptr(b_d), 1e-5, 0.1, ptr(rm), ptr(rv), None, 0, 1 if relu else 0, ptr(acc), ptr(ss),
+                                         ya.p, 1, ptr(save), st))
+    assert torch.equal(za.interior().float().cpu(), z.permute(0, 2, 3, 1))                 # z kept
+    assert _rel(ya.interior().permute(0, 3, 1, 2), yc) < 0.01
+    dz = engine.Act(N, H * stride, W * stride, C, 1, dev)
+    dgam, dbet = torch.empty(C, device=dev), torch.empty(C, device=dev)
+    coef = torch.empty(3 * C, device=dev)
+    check(lib().yolo_batchnorm_bwd(ga.p, 1, ya.p if relu else None, 1, za.p, 1, N, H, W, C, ptr(g_d), ptr(save), dz.p, dz.img_stride, stride * dz.row_stride,
+                                   stride * dz.px_stride, dz.interior_off(), 1, ptr(dgam), ptr(dbet), ptr(acc), ptr(coef), st))
+    torch.cuda.synchronize()
+    assert float(acc.abs().max()) == 0.0
+    got = dz.interior()[:, ::stride, ::stride, :].permute(0, 3, 1, 2)
+    assert _rel(got, zc.grad) < 0.01, _rel(got, zc.grad)
+    if stride == 2:
+        assert float(dz.interior()[:, 1::2, :, :].abs().max()) == 0.0 and float(dz.interior()[:, :, 1::2, :].abs().max()) == 0.0
+    assert _rel(dgam, gc.grad) < 0.005 and _rel(dbet, bc.grad) < 0.005
+    mask = (yc > 0).float() if relu else torch.ones_like(dy)
+    assert torch.equal(ga.interior().float().cpu().permute(0, 3, 1, 2), _bf(dy * mask)) or _rel(ga.interior().permute(0, 3, 1, 2), dy * mask) < 0.003
+
+
+def test_maxpool3s2_backward_matches_autograd():
+    from yolo import engine
+    from yolo._hip import lib, check, stream, PoolDesc
+    torch.manual_seed(1)
+    N, H, W, C = 3, 16, 20, 16
+    x = _bf(torch.relu(torch.randn(N, C, H, W)))
+    x[:, :, 4:7, 4:9] = 0.0                 # ties: a window of equal values gives its gradient to the first position
+    xc = x.clone().requires_grad_(True)
+    yc = torch.nn.functional.max_pool2d(xc, 3, 2, 1)
+    dy = _bf(torch.randn_like(yc))
+    yc.backward(dy)
+    dev = torch.device("cuda")
+    xa, ga, dx = engine.Act(N, H, W, C, 1, dev), engine.Act(N, H // 2, W // 2, C, 1, dev), engine.Act(N, H, W, C, 1, dev)
+    xa.interior().copy_(x.permute(0, 2, 3, 1).to(torch.bfloat16))
+    ga.interior().copy_(dy.permute(0, 2, 3, 1).to(torch.bfloat16))
+    pd = PoolDesc(N, H, W, C, 1, 1)
+    check(lib().yolo_maxpool3s2_bwd(ctypes.byref(pd), xa.p, ga.p, dx.p, 1, stream()))
+    got = dx.interior().float().cpu().permute(0, 3, 1, 2)
+    assert torch.allclose(got, _bf(xc.grad), atol=2e-2, rtol=2e-2), (got - xc.grad).abs().max()
+
+
+def _q(x):
+    """straight-through bf16 rounding: where the GPU path stores a tensor"""
+    return x + (_bf(x) - x).detach()
+
+
+def _faithful_block(blk, x):
+    """Bottleneck.forward with the GPU's storage roundings (conv outputs z and unit outputs y are bf16 buffers), so that
+    ReLU gates are decided on the same values on both sides"""
+    idn = x if blk.downsample is None else _q(blk.downsample[1](_q(blk.downsample[0](x))))
+    o = _q(torch.relu(blk.bn1(_q(blk.conv1(x)))))
+    o = _q(torch.relu(blk.bn2(_q(blk.conv2(o)))))
+    return _q(torch.relu(blk.bn3(_q(blk.conv3(o))) + idn))
+
+
+def _small_trunk():
+    """the ResNet-50 trunk's structure with one bottleneck per stage (the plan only needs trunk[0..7])"""
+    from yolo import resnet
+    torch.manual_seed(3)
+    mods = [nn.Conv2d(3, 64, 7, stride=2, padding=3, bias=False), nn.BatchNorm2d(64), nn.ReLU(inplace=True), nn.MaxPool2d(3, stride=2, padding=1),
+            resnet._make_layer(64, 64, 2, 1), resnet._make_layer(256, 128, 1, 2), resnet._make_layer(512, 256, 1, 2), resnet._make_layer(1024, 512, 1, 2)]
+    t = nn.Sequential(*mods)
+    for m in t.modules():
+        if isinstance(m, nn.BatchNorm2d):
+            nn.init.uniform_(m.weight, 0.5, 1.5)
+            nn.init.normal_(m.bias, 0.0, 0.2)
+    return t
+
+
+def test_trunk_backward_block_by_block():
+    from yolo import engine
+    trunk = _small_trunk()
+    gpu = copy.deepcopy(trunk).cuda().train()
+    plan = engine.ResNetPlan(gpu)
+    plan.trace = []
+    N = 8
+    x = torch.randn(N, 3, 128, 128)
+    params = list(gpu.parameters())
+    out = engine.ResNetTrainFunction.apply(plan, x.cuda(), *params)
+    assert out.shape == (N, 2048, 4, 4)
+    gout = torch.randn_like(out)
+    saved_blocks = None
+
+    # run backward through autograd so that .grad is filled exactly as in training
+    out.backward(gout)
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in params)
+    tr = {(k, what): g for (k, what, g) in plan.trace}
+    # blocks in forward order with the Acts that the plan still holds
+    cpu = copy.deepcopy(trunk).train()
+    with torch.no_grad():
+        for m in cpu.modules():
+            if isinstance(m, nn.Conv2d):
+                m.weight.copy_(_bf(m.weight))
+    name_of = {id(p): n for n, p in gpu.named_parameters()}
+    gpu_grads = {name_of[id(p)]: p.grad for p in params}
+    worst = {}
+    for li in range(4, 8):
+        for bi, blk in enumerate(cpu[li]):
+            u1x = plan._bufs[[k for k in plan._bufs if k[0] == ((li, bi, 1), "z")][0]]      # just to make sure the buffers exist
+            # block input = the x Act of unit 1: recover it from the previous block's output / the pooled stem
+            if (li, bi) == (4, 0):
+                xin = plan._bufs[[k for k in plan._bufs if k[0] == "pool"][0]]
+            else:
+                pli, pbi = (li, bi - 1) if bi > 0 else (li - 1, len(cpu[li - 1]) - 1)
+                xin = plan._bufs[[k for k in plan._bufs if k[0] == ((pli, pbi, 3), "y")][0]]
+            xb = xin.interior().float().cpu().permute(0, 3, 1, 2).contiguous().requires_grad_(True)
+            blk.zero_grad()
+            yb = _faithful_block(blk, xb)
+            yg = plan._bufs[[k for k in plan._bufs if k[0] == ((li, bi, 3), "y")][0]].interior().float().cpu().permute(0, 3, 1, 2)
+            assert _rel(yg, yb) < 0.02, ("forward", li, bi, _rel(yg, yb))
+            yb.backward(tr[((li, bi), "gout")].cpu())
+            r = _rel(tr[((li, bi), "gx")], xb.grad)
+            worst[("gx", li, bi)] = r
+            for n, p in blk.named_parameters():
+                full = f"{li}.{bi}.{n}"
+                r = _rel(gpu_grads[full], p.grad)
+                worst[(full,)] = r
+    assert max(worst.values()) < 0.02, {k: round(v, 4) for k, v in worst.items() if v >= 0.02}
+    # stem: conv1 + bn1 + relu + maxpool, teacher-forced with the GPU's gradient wrt the pooled map
+    xs = _bf(x).clone()
+    stem = nn.Sequential(cpu[0], cpu[1], cpu[2], cpu[3])
+    stem.zero_grad()
+    ys = cpu[3](_q(torch.relu(cpu[1](_q(cpu[0](xs))))))
+    ys.backward(tr[((4, 0), "gx")].cpu())
+    for n, p in [("0.weight", cpu[0].weight), ("1.weight", cpu[1].weight), ("1.bias", cpu[1].bias)]:
+        r = _rel(gpu_grads[n], p.grad)
+        assert r < 0.03, (n, r)
+
+
+def test_resnet_yolo_training_step_runs_and_learns():
+    """YOLOv1(ResNetBackbone(freeze=False)) -- the reference's default training model -- takes optimizer steps on the engine."""
+    from yolo import YOLOv1, ResNetBackbone, YOLOLoss
+    from yolo.optim import Adam
+    from yolo.dataset import SyntheticYOLODataset
+    torch.manual_seed(5)
+    model = YOLOv1(backbone=ResNetBackbone(pretrained=False, freeze=False)).cuda().train()
+    ds = SyntheticYOLODataset(4, seed=0)
+    x = torch.stack([ds[i][0] for i in range(4)]).cuda()
+    t = torch.stack([ds[i][1] for i in range(4)]).cuda()
+    crit = YOLOLoss()
+    opt = Adam([p for p in model.parameters() if p.requires_grad], lr=1e-4, weight_decay=5e-4, max_grad_norm=10.0)
+    losses = []
+    for _ in range(6):
+        opt.zero_grad()
+        loss, _ = crit(model(x), t)
+        loss.backward()
+        assert all(p.grad is not None for p in model.backbone.parameters())
+        opt.step()
+        losses.append(float(loss.detach()))
+    assert all(l == l for l in losses) and losses[-1] < losses[0], losses

@@ -102,11 +102,14 @@ class ResNetBackbone(Backbone):
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         if x.is_cuda:
-            if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-                raise NotImplementedError("ResNetBackbone on the HIP engine has no backward pass: freeze it (freeze=True, the "
-                                          "reference's default) or run under torch.no_grad()")
             if self._plan is None:
                 self._plan = engine.ResNetPlan(self.extractor)
+            if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+                if not self.training:
+                    raise NotImplementedError("gradients through a ResNetBackbone in eval() mode (running statistics) are not built: "
+                                              "train with model.train(), as the reference's trainer does, or freeze the backbone")
+                # trainable trunk in training mode -- the reference's default run (src/train.py:144)
+                return engine.ResNetTrainFunction.apply(self._plan, x, *self.extractor.parameters())
             if self.training:
                 # frozen but in training mode: BatchNorm uses batch statistics and updates its running statistics, exactly what
                 # the reference does (freeze does not put BN in eval; trainer.py:49 calls model.train() on everything)
