@@ -270,6 +270,31 @@ def main():
         dtr = (time.perf_counter() - t0) / 10
         resnet = {"value": round(B / dtr, 1), "unit": "images/s", "ms_per_batch": round(dtr * 1e3, 3),
                   "config": "configs[4]: YOLOv1(ResNetBackbone) batch 64 inference (BN folded) + decode + NMS conf 0.3 / nms 0.4, random init"}
+        # the reference's default TRAINING model (src/train.py:144): the same network with the trunk trainable, BatchNorm on batch statistics
+        del rm
+        torch.cuda.empty_cache()
+        from yolo.optim import Adam as HipAdam
+        tm = YOLOv1(backbone=ResNetBackbone(pretrained=False, freeze=False)).to(dev).train()
+        topt = HipAdam(tm.parameters(), lr=1e-4, weight_decay=5e-4, max_grad_norm=10.0)
+        tcrit = YOLOLoss()
+
+        def rstep():
+            topt.zero_grad(set_to_none=True)
+            ls, _ = tcrit(tm(x), tgt)
+            ls.backward()
+            topt.step()
+
+        for _ in range(2):
+            rstep()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            rstep()
+        torch.cuda.synchronize()
+        dtt = (time.perf_counter() - t0) / 5
+        resnet["train"] = {"value": round(B / dtt, 1), "unit": "images/s", "ms_per_step": round(dtt * 1e3, 3),
+                           "config": "YOLOv1(ResNetBackbone(freeze=False)) batch 64: forward (batch-statistics BatchNorm) + loss + backward + clip + Adam, random init"}
+        del tm, topt
 
     # ---------------------------------------------------------------- CPU baseline (rank 0, N=1 only)
     cpu = None

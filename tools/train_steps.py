@@ -1,24 +1,27 @@
 #!/usr/bin/env python3
 """N training steps of YOLOv1 at batch 64 (nothing else): the workload for `rocprofv3 --kernel-trace --stats`
-when only the train step's kernel mix is wanted.  usage: train_steps.py [steps]"""
+when only the train step's kernel mix is wanted.  usage: train_steps.py [steps]
+MODEL=resnet50 runs the reference's default training model instead (ResNet-50 trunk, not frozen, + DetectionHead)."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "yolo-v1_amd")); sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
 import numpy as np
 import torch
 import synth
-from yolo import YOLOv1, YOLOLoss
+from yolo import YOLOv1, YOLOLoss, ResNetBackbone
 from yolo.optim import Adam
 
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 10
 dev = torch.device("cuda")
 torch.manual_seed(0)
-model = YOLOv1().to(dev).train()
+resnet = os.environ.get("MODEL", "yolov1") == "resnet50"
+model = (YOLOv1(backbone=ResNetBackbone(pretrained=False, freeze=False)) if resnet else YOLOv1()).to(dev).train()
 x = torch.randn(64, 3, 448, 448, device=dev)
 tgt = torch.from_numpy(synth.synth_targets(64, seed=1)).to(dev)
 crit = YOLOLoss()
 opt = Adam(model.parameters(), lr=1e-4, weight_decay=5e-4, max_grad_norm=10.0)
-opt.attach_plan(model.hip_plan())
+if not resnet:
+    opt.attach_plan(model.hip_plan())
 
 
 def step():

@@ -1121,7 +1121,7 @@ class ResNetPlan:
     of a bottleneck is the epilogue of its last 1x1 conv (YOLO_EPI_BIAS_ADD_LRELU with slope 0), the stem's
     MaxPool2d(3,2,1) is yolo_maxpool3s2_fwd.  ``forward_batch_stats`` runs the same trunk with BatchNorm in training mode
     (batch statistics: conv with the raw weights, then yolo_batchnorm_train_fwd) for the FROZEN backbone of a training run;
-    the backward pass through the trunk is not built."""
+    ``forward_train`` / ``backward_train`` are the trainable trunk of the reference's default run (src/train.py:144)."""
 
     def __init__(self, trunk: nn.Sequential):
         self.trunk = trunk
