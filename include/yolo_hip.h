@@ -362,8 +362,10 @@ int yolo_clip_scale_f32(float *g, long n, const double *norm_sq, float max_norm,
  * zero-haloed NHWC bf16 conv output z [N][H+2h][W+2h][C] (C % 8 == 0).  The reference's default model trains with a
  * frozen ResNet-50 backbone whose BatchNorm layers still run in training mode (trainer.py:49): they normalise with
  * the batch mean / biased variance and update running_mean / running_var (unbiased) with `momentum`, as aten
- * batch_norm(training=True) does.  acc2c: 2*C doubles, zero on entry and on return (scratch shared by all layers);
+ * batch_norm(training=True) does.  acc2c: YOLO_BN_ACC_REPLICAS * 2*C doubles, zero on entry and on return (scratch shared
+ * by all layers; the workgroups' partial sums are spread over the replicas because same-address fp64 atomics serialise);
  * scale_shift: 2*C floats of scratch; residual: NHWC bf16 of the same H, W, C (NULL: none).  Forward only. */
+#define YOLO_BN_ACC_REPLICAS 16
 int yolo_batchnorm_train_fwd(void *z_bf16, int N, int H, int W, int C, int halo, const float *gamma, const float *beta,
                              double eps, double momentum, float *running_mean, float *running_var,
                              const void *residual_bf16, int residual_halo, int relu, double *acc2c,
@@ -379,8 +381,8 @@ int yolo_batchnorm_train_fwd(void *z_bf16, int N, int H, int W, int C, int halo,
  *   dy' = dy * [y > 0];  dbeta = sum dy';  dgamma = sum dy' * xhat;  dz = gamma * invstd * (dy' - dbeta/M - xhat * dgamma/M)
  * dz is written at dz[n*dz_img_stride + y*dz_row_stride + x*dz_px_stride + dz_off + c] (doubled strides put it
  * zero-stuffed on the input grid of a stride-2 conv, the form yolo_wgrad / the data gradient read); store_masked_dy: dy'
- * replaces dy in place (the identity branch of a bottleneck receives it).  acc2c: 2*C doubles, zero on entry and on
- * return; coef3c: 3*C floats of scratch. */
+ * replaces dy in place (the identity branch of a bottleneck receives it).  acc2c: as above (YOLO_BN_ACC_REPLICAS * 2*C
+ * doubles, zero on entry and on return); coef3c: 3*C floats of scratch. */
 int yolo_batchnorm_bwd(void *dy_bf16, int dy_halo, const void *y_bf16, int y_halo, const void *z_bf16, int z_halo,
                        int N, int H, int W, int C, const float *gamma, const float *mean_invstd, void *dz_bf16,
                        long dz_img_stride, long dz_row_stride, long dz_px_stride, long dz_off, int store_masked_dy,

@@ -316,11 +316,13 @@ def test_resnet50_variant_inference():
         for n, (rec, keep) in enumerate(res):
             r = O.decode(p01[n].cpu().numpy(), 0.3)
             assert np.array_equal(rec, r) and np.array_equal(keep, O.nms(r, 0.4, variant))
-    # an UN-frozen trunk needs a backward pass, which is not built: loud failure, no silent fallback
+    # an UN-frozen trunk trains in training mode (tests/test_gpu_resnet_train.py); gradients through the eval()-mode
+    # trunk (running statistics) are not built: loud failure, no silent fallback
     for p in g.backbone.parameters():
         p.requires_grad = True
     with pytest.raises(NotImplementedError):
-        g.train()(x.cuda())
+        g.eval()(x.cuda())
+    assert g.train()(x.cuda()).requires_grad
 
 
 def test_frozen_resnet_backbone_in_training_mode():
@@ -372,12 +374,26 @@ def test_frozen_resnet_backbone_in_training_mode():
     loss_g.backward()
     assert all(p.grad is None for p in g.backbone.parameters())
     feats = g.backbone._plan.forward_batch_stats(x.cuda()).cpu()
-    loss_c, _ = crit(m.head(feats), tgt)
+    # CPU head with the engine's storage roundings (bf16 weights, bf16 activations after every LeakyReLU), so that the
+    # LeakyReLU gates are decided on the same values on both sides -- the fp32 head differs by 8-14 % in its first conv's
+    # gradient on these chaotic random-init features, depending on nothing but rounding
+    def q(t):
+        return t + (t.to(torch.bfloat16).float() - t).detach()
+    with torch.no_grad():
+        for mod in m.head.modules():
+            if isinstance(mod, (torch.nn.Conv2d, torch.nn.Linear)):
+                mod.weight.copy_(mod.weight.to(torch.bfloat16).float())
+    h = feats
+    for mod in list(m.head.conv_layers) + list(m.head.fc_layers):
+        h = mod(h)
+        if isinstance(mod, torch.nn.LeakyReLU):
+            h = q(h)
+    loss_c, _ = crit(h.view(-1, 7, 7, 30), tgt)
     loss_c.backward()
     assert abs(loss_g.item() - loss_c.item()) < 0.02 * abs(loss_c.item())
     hg = dict(g.head.named_parameters())
     for n, pc in m.head.named_parameters():
-        assert hg[n].grad is not None and _rel(hg[n].grad, pc.grad) < 0.1, (n, _rel(hg[n].grad, pc.grad))
+        assert hg[n].grad is not None and _rel(hg[n].grad, pc.grad) < 0.08, (n, _rel(hg[n].grad, pc.grad))
 
 
 def test_gradient_arena_equals_autograd_path(model):

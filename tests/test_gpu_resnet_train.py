@@ -43,7 +43,8 @@ def test_batchnorm_backward_matches_autograd(relu, stride):
     za, ya, ga = engine.Act(N, H, W, C, 1, dev), engine.Act(N, H, W, C, 1, dev), engine.Act(N, H, W, C, 1, dev)
     za.interior().copy_(z.permute(0, 2, 3, 1).to(torch.bfloat16))
     ga.interior().copy_(dy.permute(0, 2, 3, 1).to(torch.bfloat16))
-    acc = torch.zeros(2 * C, dtype=torch.float64, device=dev)
+    from yolo._hip import BN_ACC_REPLICAS
+    acc = torch.zeros(BN_ACC_REPLICAS * 2 * C, dtype=torch.float64, device=dev)
     ss = torch.empty(2 * C, dtype=torch.float32, device=dev)
     save = torch.empty(2 * C, dtype=torch.float32, device=dev)
     rm, rv = torch.zeros(C, device=dev), torch.ones(C, device=dev)

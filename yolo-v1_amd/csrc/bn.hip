@@ -27,7 +27,33 @@ __device__ __forceinline__ void bn_unpack8(const uint4 &v, float f[8])
     f[6] = __uint_as_float(v.w << 16); f[7] = __uint_as_float(v.w & 0xffff0000u);
 }
 
-// thread = (channel group of 8, pixel lane); grid-stride over the interior pixels
+// (n, y, x) of pixel p0, p0 + stride, p0 + 2*stride, ... without a division per pixel
+struct PixIter {
+    int n, y, x, sn, sy, sx, H, W;
+    __device__ __forceinline__ PixIter(long p0, long stride, int H_, int W_) : H(H_), W(W_)
+    {
+        const long hw = (long)H_ * W_;
+        n = (int)(p0 / hw);
+        int r = (int)(p0 - (long)n * hw);
+        y = r / W_;
+        x = r - y * W_;
+        sn = (int)(stride / hw);
+        r = (int)(stride - (long)sn * hw);
+        sy = r / W_;
+        sx = r - sy * W_;
+    }
+    __device__ __forceinline__ void next()
+    {
+        x += sx;
+        if (x >= W) { x -= W; ++y; }
+        y += sy;
+        if (y >= H) { y -= H; ++n; }
+        n += sn;
+    }
+    __device__ __forceinline__ long off(int halo, int C) const { return (((long)n * (H + 2 * halo) + y + halo) * (W + 2 * halo) + x + halo) * C; }
+};
+
+// thread = (channel group of 8, pixel lane); grid-stride over the interior pixels, four independent loads in flight
 __global__ void __launch_bounds__(256) bn_stats_kernel(const bf16_t *__restrict__ z, int N, int H, int W, int C, int halo, double *__restrict__ acc)
 {
     const int C8 = C >> 3;
@@ -35,13 +61,27 @@ __global__ void __launch_bounds__(256) bn_stats_kernel(const bf16_t *__restrict_
     const int ppb = 256 / gpb;                    // pixel lanes per workgroup
     const int cg = blockIdx.x * gpb + threadIdx.x % gpb, pl = threadIdx.x / gpb;
     const long P = (long)N * H * W;
-    const int Hp = H + 2 * halo, Wp = W + 2 * halo;
     float s[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ss[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (cg < C8 && pl < ppb) {
-        for (long p = (long)blockIdx.y * ppb + pl; p < P; p += (long)gridDim.y * ppb) {
-            const int x = (int)(p % W), y = (int)((p / W) % H), n = (int)(p / ((long)W * H));
+        const long stride = (long)gridDim.y * ppb;
+        long p = (long)blockIdx.y * ppb + pl;
+        PixIter it(p < P ? p : 0, stride, H, W);
+        for (; p + 3 * stride < P; p += 4 * stride) {
+            uint4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { v[u] = *reinterpret_cast<const uint4 *>(z + it.off(halo, C) + cg * 8); it.next(); }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                float f[8];
+                bn_unpack8(v[u], f);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) { s[k] += f[k]; ss[k] += f[k] * f[k]; }
+            }
+        }
+        for (; p < P; p += stride) {
             float f[8];
-            bn_unpack8(*reinterpret_cast<const uint4 *>(z + (((long)n * Hp + y + halo) * Wp + x + halo) * C + cg * 8), f);
+            bn_unpack8(*reinterpret_cast<const uint4 *>(z + it.off(halo, C) + cg * 8), f);
+            it.next();
 #pragma unroll
             for (int k = 0; k < 8; ++k) { s[k] += f[k]; ss[k] += f[k] * f[k]; }
         }
@@ -55,8 +95,9 @@ __global__ void __launch_bounds__(256) bn_stats_kernel(const bf16_t *__restrict_
         for (int k = 0; k < 8; ++k) {
             double a = 0.0, b = 0.0;
             for (int r = 0; r < ppb; ++r) { a += red[0][r * gpb + threadIdx.x][k]; b += red[1][r * gpb + threadIdx.x][k]; }
-            atomicAdd(acc + cg * 8 + k, a);
-            atomicAdd(acc + C + cg * 8 + k, b);
+            double *rep = acc + (size_t)(blockIdx.y % YOLO_BN_ACC_REPLICAS) * 2 * C;   // same-address fp64 atomics cost ~60-150 ns each: spread them
+            atomicAdd(rep + cg * 8 + k, a);
+            atomicAdd(rep + C + cg * 8 + k, b);
         }
     }
 }
@@ -67,8 +108,15 @@ __global__ void bn_finalize_kernel(double *__restrict__ acc, int C, double count
 {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
-    const double mean = acc[c] / count;
-    double var = acc[C + c] / count - mean * mean;
+    double s1 = 0.0, s2 = 0.0;
+    for (int r = 0; r < YOLO_BN_ACC_REPLICAS; ++r) {
+        s1 += acc[(size_t)r * 2 * C + c];
+        s2 += acc[(size_t)r * 2 * C + C + c];
+        acc[(size_t)r * 2 * C + c] = 0.0;          // ready for the next layer
+        acc[(size_t)r * 2 * C + C + c] = 0.0;
+    }
+    const double mean = s1 / count;
+    double var = s2 / count - mean * mean;
     if (var < 0.0) var = 0.0;
     const double invstd = 1.0 / sqrt(var + eps);
     const double sc = (double)gamma[c] * invstd;
@@ -80,8 +128,6 @@ __global__ void bn_finalize_kernel(double *__restrict__ acc, int C, double count
         const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
         running_var[c] = (float)((1.0 - momentum) * (double)running_var[c] + momentum * unbiased);
     }
-    acc[c] = 0.0;          // ready for the next layer
-    acc[C + c] = 0.0;
 }
 
 __global__ void __launch_bounds__(256) bn_apply_kernel(bf16_t *__restrict__ z, int N, int H, int W, int C, int halo, const float *__restrict__ scale,
@@ -133,18 +179,39 @@ __global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(const bf16_t *__rest
         float mu[8], is[8];
 #pragma unroll
         for (int k = 0; k < 8; ++k) { mu[k] = mean_invstd[cg * 8 + k]; is[k] = mean_invstd[C + cg * 8 + k]; }
-        for (long p = (long)blockIdx.y * ppb + pl; p < P; p += (long)gridDim.y * ppb) {
-            const int x = (int)(p % W), y = (int)((p / W) % H), n = (int)(p / ((long)W * H));
+        const long stride = (long)gridDim.y * ppb;
+        long p = (long)blockIdx.y * ppb + pl;
+        PixIter it(p < P ? p : 0, stride, H, W);
+        auto fold = [&](const uint4 &vg, const uint4 &vz, const uint4 &va) {
             float g[8], zz[8], a[8];
-            bn_unpack8(*reinterpret_cast<const uint4 *>(dy + (((long)n * (H + 2 * dy_halo) + y + dy_halo) * (W + 2 * dy_halo) + x + dy_halo) * C + cg * 8), g);
-            bn_unpack8(*reinterpret_cast<const uint4 *>(z + (((long)n * (H + 2 * z_halo) + y + z_halo) * (W + 2 * z_halo) + x + z_halo) * C + cg * 8), zz);
+            bn_unpack8(vg, g);
+            bn_unpack8(vz, zz);
             if (yact) {
-                bn_unpack8(*reinterpret_cast<const uint4 *>(yact + (((long)n * (H + 2 * y_halo) + y + y_halo) * (W + 2 * y_halo) + x + y_halo) * C + cg * 8), a);
+                bn_unpack8(va, a);
 #pragma unroll
                 for (int k = 0; k < 8; ++k) g[k] = a[k] > 0.0f ? g[k] : 0.0f;
             }
 #pragma unroll
             for (int k = 0; k < 8; ++k) { s[k] += g[k]; ss[k] += g[k] * ((zz[k] - mu[k]) * is[k]); }
+        };
+        for (; p + 1 * stride < P; p += 2 * stride) {      // two pixels = six independent 16-B loads in flight
+            uint4 vg[2], vz[2], va[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                vg[u] = *reinterpret_cast<const uint4 *>(dy + it.off(dy_halo, C) + cg * 8);
+                vz[u] = *reinterpret_cast<const uint4 *>(z + it.off(z_halo, C) + cg * 8);
+                va[u] = yact ? *reinterpret_cast<const uint4 *>(yact + it.off(y_halo, C) + cg * 8) : uint4{0, 0, 0, 0};
+                it.next();
+            }
+            fold(vg[0], vz[0], va[0]);
+            fold(vg[1], vz[1], va[1]);
+        }
+        for (; p < P; p += stride) {
+            const uint4 vg = *reinterpret_cast<const uint4 *>(dy + it.off(dy_halo, C) + cg * 8);
+            const uint4 vz = *reinterpret_cast<const uint4 *>(z + it.off(z_halo, C) + cg * 8);
+            const uint4 va = yact ? *reinterpret_cast<const uint4 *>(yact + it.off(y_halo, C) + cg * 8) : uint4{0, 0, 0, 0};
+            it.next();
+            fold(vg, vz, va);
         }
     }
     __shared__ float red[2][256][9];
@@ -156,8 +223,9 @@ __global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(const bf16_t *__rest
         for (int k = 0; k < 8; ++k) {
             double a = 0.0, b = 0.0;
             for (int r = 0; r < ppb; ++r) { a += red[0][r * gpb + threadIdx.x][k]; b += red[1][r * gpb + threadIdx.x][k]; }
-            atomicAdd(acc + cg * 8 + k, a);
-            atomicAdd(acc + C + cg * 8 + k, b);
+            double *rep = acc + (size_t)(blockIdx.y % YOLO_BN_ACC_REPLICAS) * 2 * C;   // same-address fp64 atomics cost ~60-150 ns each: spread them
+            atomicAdd(rep + cg * 8 + k, a);
+            atomicAdd(rep + C + cg * 8 + k, b);
         }
     }
 }
@@ -167,14 +235,18 @@ __global__ void bn_bwd_finalize_kernel(double *__restrict__ acc, int C, double c
 {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
-    const double s1 = acc[c], s2 = acc[C + c];
+    double s1 = 0.0, s2 = 0.0;
+    for (int r = 0; r < YOLO_BN_ACC_REPLICAS; ++r) {
+        s1 += acc[(size_t)r * 2 * C + c];
+        s2 += acc[(size_t)r * 2 * C + C + c];
+        acc[(size_t)r * 2 * C + c] = 0.0;
+        acc[(size_t)r * 2 * C + C + c] = 0.0;
+    }
     dbeta[c] = (float)s1;
     dgamma[c] = (float)s2;
     coef[c] = gamma[c] * mean_invstd[C + c];
     coef[C + c] = (float)(s1 / count);
     coef[2 * C + c] = (float)(s2 / count);
-    acc[c] = 0.0;
-    acc[C + c] = 0.0;
 }
 
 __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(bf16_t *__restrict__ dy, int dy_halo, const bf16_t *__restrict__ yact, int y_halo,
@@ -227,7 +299,7 @@ YOLO_API int yolo_batchnorm_train_fwd(void *z, int N, int H, int W, int C, int h
     hipStream_t s = STRM(stream);
     const int C8 = C / 8, gpb = C8 < 256 ? C8 : 256, ppb = 256 / gpb;
     const long P = (long)N * H * W;
-    long gy = (P + (long)ppb * 64 - 1) / ((long)ppb * 64);     // ~64 pixels per thread
+    long gy = (P + (long)ppb * 32 - 1) / ((long)ppb * 32);     // ~32 pixels per thread
     if (gy > 2048) gy = 2048;
     if (gy < 1) gy = 1;
     hipLaunchKernelGGL(bn_stats_kernel, dim3((C8 + gpb - 1) / gpb, (unsigned)gy), dim3(256), 0, s, (const bf16_t *)z, N, H, W, C, halo, acc2c);
@@ -253,7 +325,7 @@ YOLO_API int yolo_batchnorm_bwd(void *dy, int dy_halo, const void *y, int y_halo
     hipStream_t s = STRM(stream);
     const int C8 = C / 8, gpb = C8 < 256 ? C8 : 256, ppb = 256 / gpb;
     const long P = (long)N * H * W;
-    long gy = (P + (long)ppb * 64 - 1) / ((long)ppb * 64);
+    long gy = (P + (long)ppb * 32 - 1) / ((long)ppb * 32);
     if (gy > 2048) gy = 2048;
     if (gy < 1) gy = 1;
     hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3((C8 + gpb - 1) / gpb, (unsigned)gy), dim3(256), 0, s, (const bf16_t *)dy, dy_halo, (const bf16_t *)y, y_halo,

@@ -16,6 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libyolo_hip.so")
 _LIB = None
 
+BN_ACC_REPLICAS = 16         # YOLO_BN_ACC_REPLICAS (include/yolo_hip.h)
 c_int, c_long, c_float, c_double, c_void_p = ctypes.c_int, ctypes.c_long, ctypes.c_float, ctypes.c_double, ctypes.c_void_p
 
 

@@ -1204,7 +1204,7 @@ class ResNetPlan:
         """BatchNorm with batch statistics (+ residual, + ReLU) in place on the conv output, running statistics updated."""
         C = a.C
         if self._bn_scratch is None or self._bn_scratch[0].device != dev:
-            self._bn_scratch = (torch.zeros(2 * 2048, dtype=torch.float64, device=dev), torch.empty(2 * 2048, dtype=torch.float32, device=dev))
+            self._bn_scratch = (torch.zeros(_hip.BN_ACC_REPLICAS * 2 * 2048, dtype=torch.float64, device=dev), torch.empty(2 * 2048, dtype=torch.float32, device=dev))
         acc, ss = self._bn_scratch
         if C > 2048 or bn.weight is None or not bn.track_running_stats:
             raise NotImplementedError("batch-statistics BatchNorm: affine layers with running statistics and C <= 2048")
