@@ -154,52 +154,80 @@ YOLO_API int yolo_maxpool2_bwd_lrelu(const yolo_pool_desc *d, const void *yfull,
 
 namespace yolo {
 
-// MaxPool2d(3, stride 2, pad 1) backward, gather form (deterministic, no atomics): one thread = one INPUT pixel x 8
-// channels.  Row h belongs to window rows h/2 (always) and (h+1)/2 (odd h); likewise columns: at most four windows.
-// For each of them the thread re-reads the window and takes the window's gradient iff its own pixel is the arg-max --
-// the FIRST maximum in row-major scan order over the in-range positions, as aten's max_pool2d_with_indices keeps it.
+// MaxPool2d(3, stride 2, pad 1) backward, gather form (deterministic, no atomics): one thread = one 2x2 block of INPUT
+// pixels (rows 2i, 2i+1; columns 2j, 2j+1) x 8 channels.  Exactly four windows touch the block -- (i, j), (i, j+1),
+// (i+1, j), (i+1, j+1) -- and for each the thread re-reads the window, finds its arg-max (the FIRST maximum in row-major
+// order over the in-range positions, as aten's max_pool2d_with_indices keeps it) and, when that lies inside the block,
+// adds the window's gradient to that pixel: 9 loads per input pixel instead of ~20 for a thread per pixel.
 __global__ void __launch_bounds__(256) maxpool3s2_bwd_kernel(const bf16_t *__restrict__ x, const bf16_t *__restrict__ dy, int N, int H, int W, int C, int hi,
                                                              int ho, int hd, bf16_t *__restrict__ dx)
 {
-    const int C8 = C >> 3, Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
-    const long total = (long)N * H * W * C8;
+    const int C8 = C >> 3, Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1, Hb = (H + 1) / 2, Wb = (W + 1) / 2;
+    const long total = (long)N * Hb * Wb * C8;
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= total) return;
     const int c8 = (int)(idx % C8);
-    const int w = (int)((idx / C8) % W);
-    const int h = (int)((idx / ((long)C8 * W)) % H);
-    const int n = (int)(idx / ((long)C8 * W * H));
+    const int j = (int)((idx / C8) % Wb);
+    const int i = (int)((idx / ((long)C8 * Wb)) % Hb);
+    const int n = (int)(idx / ((long)C8 * Wb * Hb));
     const int Wp = W + 2 * hi, Hp = H + 2 * hi, Wop = Wo + 2 * ho, Hop = Ho + 2 * ho, Wdp = W + 2 * hd, Hdp = H + 2 * hd;
     const bf16_t *xb = x + ((long)n * Hp * Wp) * C + c8 * 8;
-    float mine[8], acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    unpack8(*reinterpret_cast<const uint4 *>(xb + ((long)(h + hi) * Wp + w + hi) * C), mine);
+    float acc[2][2][8];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int k = 0; k < 8; ++k) acc[a][b][k] = 0.0f;
+#pragma unroll
     for (int a = 0; a < 2; ++a) {
-        const int oy = (h + a) >> 1;
-        if ((a == 1 && !(h & 1)) || oy >= Ho) continue;
+        const int oy = i + a;
+        if (oy >= Ho) continue;
+#pragma unroll
         for (int b = 0; b < 2; ++b) {
-            const int ox = (w + b) >> 1;
-            if ((b == 1 && !(w & 1)) || ox >= Wo) continue;
-            bool first[8] = {true, true, true, true, true, true, true, true};
+            const int ox = j + b;
+            if (ox >= Wo) continue;
+            // arg-max of window (oy, ox): position code ky*3+kx of the first maximum, per channel
+            float best[8];
+            int arg[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { best[k] = -3.4e38f; arg[k] = -1; }
+#pragma unroll
             for (int ky = 0; ky < 3; ++ky) {
                 const int yy = 2 * oy - 1 + ky;
                 if (yy < 0 || yy >= H) continue;
+#pragma unroll
                 for (int kx = 0; kx < 3; ++kx) {
                     const int xx = 2 * ox - 1 + kx;
-                    if (xx < 0 || xx >= W || (yy == h && xx == w)) continue;
+                    if (xx < 0 || xx >= W) continue;
                     float v[8];
                     unpack8(*reinterpret_cast<const uint4 *>(xb + ((long)(yy + hi) * Wp + xx + hi) * C), v);
-                    const bool before = yy < h || (yy == h && xx < w);
 #pragma unroll
-                    for (int k = 0; k < 8; ++k) first[k] = first[k] && (before ? v[k] < mine[k] : v[k] <= mine[k]);
+                    for (int k = 0; k < 8; ++k)
+                        if (v[k] > best[k]) { best[k] = v[k]; arg[k] = ky * 3 + kx; }
                 }
             }
             float g[8];
             unpack8(*reinterpret_cast<const uint4 *>(dy + (((long)n * Hop + oy + ho) * Wop + ox + ho) * C + c8 * 8), g);
+            // block pixel (r, c) = input (2i + r, 2j + c) sits at window position (ky, kx) = (2i + r - 2oy + 1, 2j + c - 2ox + 1)
 #pragma unroll
-            for (int k = 0; k < 8; ++k) acc[k] += first[k] ? g[k] : 0.0f;
+            for (int r = 0; r < 2; ++r)
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    const int ky = r - 2 * a + 1, kx = c - 2 * b + 1;
+                    if (ky < 0 || ky > 2 || kx < 0 || kx > 2) continue;
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) acc[r][c][k] += arg[k] == ky * 3 + kx ? g[k] : 0.0f;
+                }
         }
     }
-    *reinterpret_cast<uint4 *>(dx + (((long)n * Hdp + h + hd) * Wdp + w + hd) * C + c8 * 8) = pack8(acc);
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const int h = 2 * i + r, w = 2 * j + c;
+            if (h < H && w < W) *reinterpret_cast<uint4 *>(dx + (((long)n * Hdp + h + hd) * Wdp + w + hd) * C + c8 * 8) = pack8(acc[r][c]);
+        }
 }
 
 }  // namespace yolo
@@ -209,7 +237,7 @@ YOLO_API int yolo_maxpool3s2_bwd(const yolo_pool_desc *d, const void *x, const v
     if (!d || !x || !dy || !dx || d->N <= 0 || d->H <= 0 || d->W <= 0 || d->C <= 0 || d->in_halo < 0 || d->out_halo < 0 || dx_halo < 0)
         return fail(YOLO_E_ARG, "yolo_maxpool3s2_bwd: bad argument");
     if (d->C & 7) return fail(YOLO_E_UNSUPPORTED, "yolo_maxpool3s2_bwd: C must be a multiple of 8");
-    const long total = (long)d->N * d->H * d->W * (d->C / 8);
+    const long total = (long)d->N * ((d->H + 1) / 2) * ((d->W + 1) / 2) * (d->C / 8);
     hipLaunchKernelGGL(maxpool3s2_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, STRM(stream), (const bf16_t *)x, (const bf16_t *)dy, d->N, d->H,
                        d->W, d->C, d->in_halo, d->out_halo, dx_halo, (bf16_t *)dx);
     return check_launch("yolo_maxpool3s2_bwd");
