@@ -200,3 +200,9 @@ def test_resnet_yolo_training_step_runs_and_learns():
         opt.step()
         losses.append(float(loss.detach()))
     assert all(l == l for l in losses) and losses[-1] < losses[0], losses
+    # two forwards before a backward would share activation buffers: refused loudly, not computed wrongly
+    l1, _ = crit(model(x), t)
+    l2, _ = crit(model(x), t)
+    with pytest.raises(RuntimeError, match="one forward in flight"):
+        l1.backward()
+    l2.backward()

@@ -1381,13 +1381,17 @@ class ResNetPlan:
                 cur = u3["y"]
         out = torch.empty((N, cur.C, cur.H, cur.W), dtype=torch.float32, device=dev)
         check(lib().yolo_nhwc_bf16_to_nchw_f32(cur.p, N, cur.C, cur.H, cur.W, cur.halo, ptr(out), st), "nhwc->nchw")
-        return out, {"N": N, "dev": dev, "stem": stem, "blocks": blocks, "out": cur}
+        self._train_gen = getattr(self, "_train_gen", 0) + 1
+        return out, {"N": N, "dev": dev, "stem": stem, "blocks": blocks, "out": cur, "gen": self._train_gen}
 
     def backward_train(self, saved, gout: torch.Tensor) -> dict:
         """gradients of every trunk parameter for the forward recorded in `saved`: {parameter: fp32 gradient}."""
         L_ = lib()
         st = stream()
         N, dev = saved["N"], saved["dev"]
+        if saved["gen"] != self._train_gen:
+            raise RuntimeError("ResNetPlan: a later training forward has reused this forward's activation buffers -- call backward() "
+                               "before the next forward of the same backbone (one forward in flight per plan)")
         acc, _ = self._bn_scratch
         if getattr(self, "_coef", None) is None or self._coef.device != dev:
             self._coef = torch.empty(3 * 2048, dtype=torch.float32, device=dev)
