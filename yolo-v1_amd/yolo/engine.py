@@ -1273,23 +1273,32 @@ class ResNetPlan:
 
     # ------------------------------------------------------------------ trainable trunk (forward keeps z, backward)
     def _pack_train(self):
-        """bf16 forward AND data-gradient operands of the raw conv weights (the stem needs no data gradient)."""
+        """bf16 forward AND data-gradient operands of the raw conv weights (the stem needs no data gradient); refreshed with
+        yolo_pack_conv_weights_multi, 32 layers per launch, whenever a weight changed"""
         ver = tuple(int(p._version) for n, p in self.trunk.named_parameters() if p.dim() == 4)
         if getattr(self, "_train_pk", None) is not None and self._train_pk[0] == ver:
             return self._train_pk[1]
         st = stream()
-        out = {}
+        out = self._train_pk[1] if getattr(self, "_train_pk", None) is not None else {}
+        items = []
 
         def pack(name, conv, bn, first=False):
-            w = conv.weight.detach().float().contiguous()
+            w = conv.weight.detach()
+            if w.dtype != torch.float32 or not w.is_contiguous():
+                w = w.float().contiguous()
             co, ci, k, _ = w.shape
-            if first:
-                wf = torch.empty((co, 7, 8, 4), dtype=torch.bfloat16, device=w.device)
-                check(lib().yolo_pack_conv_weight(ptr(w), co, 3, 7, 7, 4, 8, ptr(wf), None, st), "pack stem")
-                wd = None
+            if name in out:
+                wf, wd = out[name][0], out[name][1]
+            elif first:
+                wf, wd = torch.empty((co, 7, 8, 4), dtype=torch.bfloat16, device=w.device), None
             else:
                 wf = torch.empty((co, k, k, ci), dtype=torch.bfloat16, device=w.device)
                 wd = torch.empty((ci, k, k, co), dtype=torch.bfloat16, device=w.device)
+            if first:
+                check(lib().yolo_pack_conv_weight(ptr(w), co, 3, 7, 7, 4, 8, ptr(wf), None, st), "pack stem")
+            elif co % 64 == 0 and ci % 64 == 0:
+                items.append((ConvPackItem(w.data_ptr(), wf.data_ptr(), wd.data_ptr(), co, ci, k, k), w))
+            else:
                 check(lib().yolo_pack_conv_weight(ptr(w), co, ci, k, k, ci, k, ptr(wf), ptr(wd), st), "pack")
             out[name] = (wf, wd, conv, bn)
 
@@ -1301,6 +1310,9 @@ class ResNetPlan:
                 pack((li, bi, 3), blk.conv3, blk.bn3)
                 if blk.downsample is not None:
                     pack((li, bi, "d"), blk.downsample[0], blk.downsample[1])
+        for i in range(0, len(items), 32):
+            tab = (ConvPackItem * len(items[i: i + 32]))(*[it[0] for it in items[i: i + 32]])
+            check(lib().yolo_pack_conv_weights_multi(tab, len(items[i: i + 32]), st), "pack_conv_weights_multi")
         self._train_pk = (ver, out)
         return out
 
