@@ -372,12 +372,15 @@ int yolo_batchnorm_train_fwd(void *z_bf16, int N, int H, int W, int C, int halo,
                              float *scale_shift, void *out_bf16, int out_halo, float *save_mean_invstd,
                              yolo_stream_t stream);
 /* (out_bf16 != NULL: the result goes to that buffer [N][H+2*out_halo][W+2*out_halo][C] and z is kept -- a trainable
- *  trunk needs z for the backward pass; save_mean_invstd != NULL: 2*C floats, batch mean then 1/sqrt(var + eps).)
+ *  trunk needs z for the backward pass; save_mean_invstd != NULL: 4*C floats -- batch mean, 1/sqrt(var + eps), and the
+ *  scale / shift the forward applied, y = fma(z, scale, shift).)
  *
  * BatchNorm2d backward (training mode) for a conv -> BN [-> + residual] [-> ReLU] unit of a TRAINABLE ResNet trunk
  * (the reference's default run: ResNetBackbone(pretrained=True, freeze=False), src/train.py:144; aten
  * native_batch_norm_backward + threshold_backward).  dy: gradient wrt the unit's output; y: that output (ReLU mask,
- * NULL when the unit has no ReLU); z: the conv output the forward normalised; mean_invstd: as saved by the forward.
+ * NULL when the unit has no ReLU, or with relu_from_z = 1: the unit is conv -> BN -> ReLU without a residual and the mask is
+ * recomputed as fma(z, scale, shift) > 0, the forward's own expression, which saves reading y twice);
+ * z: the conv output the forward normalised; mean_invstd: the 4*C floats saved by the forward.
  *   dy' = dy * [y > 0];  dbeta = sum dy';  dgamma = sum dy' * xhat;  dz = gamma * invstd * (dy' - dbeta/M - xhat * dgamma/M)
  * dz is written at dz[n*dz_img_stride + y*dz_row_stride + x*dz_px_stride + dz_off + c] (doubled strides put it
  * zero-stuffed on the input grid of a stride-2 conv, the form yolo_wgrad / the data gradient read); store_masked_dy: dy'
@@ -386,7 +389,7 @@ int yolo_batchnorm_train_fwd(void *z_bf16, int N, int H, int W, int C, int halo,
 int yolo_batchnorm_bwd(void *dy_bf16, int dy_halo, const void *y_bf16, int y_halo, const void *z_bf16, int z_halo,
                        int N, int H, int W, int C, const float *gamma, const float *mean_invstd, void *dz_bf16,
                        long dz_img_stride, long dz_row_stride, long dz_px_stride, long dz_off, int store_masked_dy,
-                       float *dgamma, float *dbeta, double *acc2c, float *coef3c, yolo_stream_t stream);
+                       int relu_from_z, float *dgamma, float *dbeta, double *acc2c, float *coef3c, yolo_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * TP / FP matching of mAPMetric on the device.  Replaces the per-class greedy matching loops of

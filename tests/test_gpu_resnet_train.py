@@ -22,8 +22,8 @@ def _rel(a, b):
     return ((a - b).norm() / (b.norm() + 1e-20)).item()
 
 
-@pytest.mark.parametrize("relu,stride", [(True, 1), (False, 1), (True, 2)])
-def test_batchnorm_backward_matches_autograd(relu, stride):
+@pytest.mark.parametrize("relu,stride,from_z", [(True, 1, False), (False, 1, False), (True, 2, False), (True, 1, True)])
+def test_batchnorm_backward_matches_autograd(relu, stride, from_z):
     from yolo import engine
     from yolo._hip import lib, check, ptr, stream
     torch.manual_seed(0)
@@ -46,7 +46,7 @@ def test_batchnorm_backward_matches_autograd(relu, stride):
     from yolo._hip import BN_ACC_REPLICAS
     acc = torch.zeros(BN_ACC_REPLICAS * 2 * C, dtype=torch.float64, device=dev)
     ss = torch.empty(2 * C, dtype=torch.float32, device=dev)
-    save = torch.empty(2 * C, dtype=torch.float32, device=dev)
+    save = torch.empty(4 * C, dtype=torch.float32, device=dev)
     rm, rv = torch.zeros(C, device=dev), torch.ones(C, device=dev)
     g_d, b_d = gamma.to(dev), beta.to(dev)
     check(lib().yolo_batchnorm_train_fwd(za.p, N, H, W, C, 1, ptr(g_d), ptr(b_d), 1e-5, 0.1, ptr(rm), ptr(rv), None, 0, 1 if relu else 0, ptr(acc), ptr(ss),
@@ -56,8 +56,9 @@ def test_batchnorm_backward_matches_autograd(relu, stride):
     dz = engine.Act(N, H * stride, W * stride, C, 1, dev)
     dgam, dbet = torch.empty(C, device=dev), torch.empty(C, device=dev)
     coef = torch.empty(3 * C, device=dev)
-    check(lib().yolo_batchnorm_bwd(ga.p, 1, ya.p if relu else None, 1, za.p, 1, N, H, W, C, ptr(g_d), ptr(save), dz.p, dz.img_stride, stride * dz.row_stride,
-                                   stride * dz.px_stride, dz.interior_off(), 1, ptr(dgam), ptr(dbet), ptr(acc), ptr(coef), st))
+    check(lib().yolo_batchnorm_bwd(ga.p, 1, ya.p if (relu and not from_z) else None, 1, za.p, 1, N, H, W, C, ptr(g_d), ptr(save), dz.p, dz.img_stride,
+                                   stride * dz.row_stride, stride * dz.px_stride, dz.interior_off(), 1, 1 if from_z else 0, ptr(dgam), ptr(dbet), ptr(acc),
+                                   ptr(coef), st))
     torch.cuda.synchronize()
     assert float(acc.abs().max()) == 0.0
     got = dz.interior()[:, ::stride, ::stride, :].permute(0, 3, 1, 2)

@@ -122,7 +122,10 @@ __global__ void bn_finalize_kernel(double *__restrict__ acc, int C, double count
     const double sc = (double)gamma[c] * invstd;
     scale[c] = (float)sc;
     shift[c] = (float)((double)beta[c] - mean * sc);
-    if (save_mean_invstd) { save_mean_invstd[c] = (float)mean; save_mean_invstd[C + c] = (float)invstd; }
+    if (save_mean_invstd) {     // [mean | invstd | scale | shift]: the backward recomputes a ReLU mask from z with the forward's own scale / shift
+        save_mean_invstd[c] = (float)mean; save_mean_invstd[C + c] = (float)invstd;
+        save_mean_invstd[2 * C + c] = scale[c]; save_mean_invstd[3 * C + c] = shift[c];
+    }
     if (running_mean) {
         running_mean[c] = (float)((1.0 - momentum) * (double)running_mean[c] + momentum * mean);
         const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
@@ -152,7 +155,7 @@ __global__ void __launch_bounds__(256) bn_apply_kernel(bf16_t *__restrict__ z, i
     unsigned o[4];
 #pragma unroll
     for (int k = 0; k < 8; k += 2) {
-        float a = f[k] * scale[cg * 8 + k] + shift[cg * 8 + k], b = f[k + 1] * scale[cg * 8 + k + 1] + shift[cg * 8 + k + 1];
+        float a = fmaf(f[k], scale[cg * 8 + k], shift[cg * 8 + k]), b = fmaf(f[k + 1], scale[cg * 8 + k + 1], shift[cg * 8 + k + 1]);
         if (residual) { a += r[k]; b += r[k + 1]; }
         if (relu) { a = a > 0.0f ? a : 0.0f; b = b > 0.0f ? b : 0.0f; }
         o[k >> 1] = (unsigned)f32_to_bf16(a) | ((unsigned)f32_to_bf16(b) << 16);
@@ -167,7 +170,7 @@ __global__ void __launch_bounds__(256) bn_apply_kernel(bf16_t *__restrict__ z, i
 // ---- backward.  dy' = dy (masked by y > 0 when the unit ends in a ReLU); all of dy, y, z are [N][H+2h][W+2h][C].
 __global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(const bf16_t *__restrict__ dy, int dy_halo, const bf16_t *__restrict__ yact, int y_halo,
                                                             const bf16_t *__restrict__ z, int z_halo, int N, int H, int W, int C,
-                                                            const float *__restrict__ mean_invstd, double *__restrict__ acc)
+                                                            const float *__restrict__ mean_invstd, double *__restrict__ acc, int mask_from_z)
 {
     const int C8 = C >> 3;
     const int gpb = C8 < 256 ? C8 : 256;
@@ -176,9 +179,12 @@ __global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(const bf16_t *__rest
     const long P = (long)N * H * W;
     float s[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ss[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (cg < C8 && pl < ppb) {
-        float mu[8], is[8];
+        float mu[8], is[8], sc[8], sh[8];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) { mu[k] = mean_invstd[cg * 8 + k]; is[k] = mean_invstd[C + cg * 8 + k]; }
+        for (int k = 0; k < 8; ++k) {
+            mu[k] = mean_invstd[cg * 8 + k]; is[k] = mean_invstd[C + cg * 8 + k];
+            sc[k] = mask_from_z ? mean_invstd[2 * C + cg * 8 + k] : 0.0f; sh[k] = mask_from_z ? mean_invstd[3 * C + cg * 8 + k] : 0.0f;
+        }
         const long stride = (long)gridDim.y * ppb;
         long p = (long)blockIdx.y * ppb + pl;
         PixIter it(p < P ? p : 0, stride, H, W);
@@ -190,6 +196,9 @@ __global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(const bf16_t *__rest
                 bn_unpack8(va, a);
 #pragma unroll
                 for (int k = 0; k < 8; ++k) g[k] = a[k] > 0.0f ? g[k] : 0.0f;
+            } else if (mask_from_z) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) g[k] = fmaf(zz[k], sc[k], sh[k]) > 0.0f ? g[k] : 0.0f;     // the forward's own expression
             }
 #pragma unroll
             for (int k = 0; k < 8; ++k) { s[k] += g[k]; ss[k] += g[k] * ((zz[k] - mu[k]) * is[k]); }
@@ -252,7 +261,7 @@ __global__ void bn_bwd_finalize_kernel(double *__restrict__ acc, int C, double c
 __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(bf16_t *__restrict__ dy, int dy_halo, const bf16_t *__restrict__ yact, int y_halo,
                                                            const bf16_t *__restrict__ z, int z_halo, int N, int H, int W, int C,
                                                            const float *__restrict__ mean_invstd, const float *__restrict__ coef, bf16_t *__restrict__ dz,
-                                                           long dz_img, long dz_row, long dz_px, long dz_off, int store_masked)
+                                                           long dz_img, long dz_row, long dz_px, long dz_off, int store_masked, int mask_from_z)
 {
     const int C8 = C >> 3;
     const long total = (long)N * H * W * C8;
@@ -269,6 +278,9 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(bf16_t *__restrict__ 
         bn_unpack8(*reinterpret_cast<const uint4 *>(yact + (((long)n * (H + 2 * y_halo) + y + y_halo) * (W + 2 * y_halo) + x + y_halo) * C + cg * 8), a);
 #pragma unroll
         for (int k = 0; k < 8; ++k) g[k] = a[k] > 0.0f ? g[k] : 0.0f;
+    } else if (mask_from_z) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) g[k] = fmaf(zz[k], mean_invstd[2 * C + cg * 8 + k], mean_invstd[3 * C + cg * 8 + k]) > 0.0f ? g[k] : 0.0f;
     }
     unsigned o[4], m[4];
 #pragma unroll
@@ -315,11 +327,11 @@ YOLO_API int yolo_batchnorm_train_fwd(void *z, int N, int H, int W, int C, int h
 
 YOLO_API int yolo_batchnorm_bwd(void *dy, int dy_halo, const void *y, int y_halo, const void *z, int z_halo, int N, int H, int W, int C, const float *gamma,
                                 const float *mean_invstd, void *dz, long dz_img_stride, long dz_row_stride, long dz_px_stride, long dz_off, int store_masked_dy,
-                                float *dgamma, float *dbeta, double *acc2c, float *coef3c, yolo_stream_t stream)
+                                int relu_from_z, float *dgamma, float *dbeta, double *acc2c, float *coef3c, yolo_stream_t stream)
 {
     if (!dy || !z || !gamma || !mean_invstd || !dz || !dgamma || !dbeta || !acc2c || !coef3c || N <= 0 || H <= 0 || W <= 0 || C <= 0 || dy_halo < 0 || y_halo < 0 ||
-        z_halo < 0)
-        return fail(YOLO_E_ARG, "yolo_batchnorm_bwd: bad argument");
+        z_halo < 0 || (relu_from_z && y))
+        return fail(YOLO_E_ARG, "yolo_batchnorm_bwd: bad argument (relu_from_z excludes y)");
     if ((C & 7) || (dz_img_stride & 7) || (dz_row_stride & 7) || (dz_px_stride & 7) || (dz_off & 7))
         return fail(YOLO_E_UNSUPPORTED, "yolo_batchnorm_bwd: C = %d and the dz strides must be multiples of 8", C);
     hipStream_t s = STRM(stream);
@@ -329,12 +341,12 @@ YOLO_API int yolo_batchnorm_bwd(void *dy, int dy_halo, const void *y, int y_halo
     if (gy > 2048) gy = 2048;
     if (gy < 1) gy = 1;
     hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3((C8 + gpb - 1) / gpb, (unsigned)gy), dim3(256), 0, s, (const bf16_t *)dy, dy_halo, (const bf16_t *)y, y_halo,
-                       (const bf16_t *)z, z_halo, N, H, W, C, mean_invstd, acc2c);
+                       (const bf16_t *)z, z_halo, N, H, W, C, mean_invstd, acc2c, relu_from_z);
     if (int rc = check_launch("yolo_batchnorm_bwd(reduce)")) return rc;
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, s, acc2c, C, (double)P, gamma, mean_invstd, dgamma, dbeta, coef3c);
     if (int rc = check_launch("yolo_batchnorm_bwd(finalize)")) return rc;
     const long total = P * C8;
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (bf16_t *)dy, dy_halo, (const bf16_t *)y, y_halo, (const bf16_t *)z,
-                       z_halo, N, H, W, C, mean_invstd, coef3c, (bf16_t *)dz, dz_img_stride, dz_row_stride, dz_px_stride, dz_off, store_masked_dy);
+                       z_halo, N, H, W, C, mean_invstd, coef3c, (bf16_t *)dz, dz_img_stride, dz_row_stride, dz_px_stride, dz_off, store_masked_dy, relu_from_z);
     return check_launch("yolo_batchnorm_bwd(apply)");
 }

@@ -95,7 +95,7 @@ _SIGS = {
     "yolo_batchnorm_train_fwd": [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_double, c_double, c_void_p, c_void_p, c_void_p, c_int,
                                  c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p],
     "yolo_batchnorm_bwd": [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, ctypes.c_long, ctypes.c_long,
-                           ctypes.c_long, ctypes.c_long, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
+                           ctypes.c_long, ctypes.c_long, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
     "yolo_map_match": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, ctypes.POINTER(c_double), c_int, c_double, c_double, c_double,
                        c_void_p, c_void_p, c_void_p],
     "yolo_pairwise_iou": [c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p],

@@ -1333,7 +1333,8 @@ class ResNetPlan:
         with _timed(str(tag), "igemm", 2.0 * N * Ho * Wo * conv.out_channels * conv.in_channels * k * k):
             igemm_call(d, a_in.p, ptr(wf), None, None, z.p, st, f"igemm {tag}")
         self._bn_train(z, bn, relu, residual, dev, st, out=y, save=stats)
-        return {"tag": tag, "conv": conv, "bn": bn, "x": a_in, "z": z, "y": y, "relu": relu, "stats": stats, "wd": wd, "k": k, "s": s, "p": p}
+        return {"tag": tag, "conv": conv, "bn": bn, "x": a_in, "z": z, "y": y, "relu": relu, "res": residual is not None, "stats": stats, "wd": wd,
+                "k": k, "s": s, "p": p}
 
     def forward_train(self, x: torch.Tensor):
         """Training-mode forward of a TRAINABLE trunk (the reference's default run, src/train.py:144: ResNetBackbone(freeze=False)):
@@ -1350,14 +1351,14 @@ class ResNetPlan:
         Ho, Wo = (H + 6 - 7) // 2 + 1, (W + 6 - 7) // 2 + 1
         if Ho % 8 or Wo % 16:
             raise NotImplementedError("trainable ResNet trunk: the stem's weight-gradient kernel needs an input of (16k) x (32k) pixels")
-        nstat = 2 * (64 + sum(u.num_features for u in self.trunk.modules() if isinstance(u, nn.BatchNorm2d)))
+        nstat = 4 * (64 + sum(u.num_features for u in self.trunk.modules() if isinstance(u, nn.BatchNorm2d)))
         if getattr(self, "_stats", None) is None or self._stats.numel() < nstat or self._stats.device != dev:
             self._stats = torch.empty(nstat, dtype=torch.float32, device=dev)
         cursor = [0]
 
         def stat(C):
-            t = self._stats[cursor[0]: cursor[0] + 2 * C]
-            cursor[0] += 2 * C
+            t = self._stats[cursor[0]: cursor[0] + 4 * C]
+            cursor[0] += 4 * C
             return t
 
         a = self._act("in", N, H, W, 4, 3, dev)
@@ -1372,7 +1373,7 @@ class ResNetPlan:
         d.out_img_stride, d.out_row_stride, d.out_px_stride, d.out_off = z0.img_stride, z0.row_stride, z0.px_stride, z0.interior_off()
         d.epilogue, d.slope = EPI_NONE, 1.0
         _igemm(lib(), d, a.p, ptr(wf), None, None, z0.p, st, "igemm stem")
-        stem = {"tag": "stem", "conv": conv, "bn": bn, "x": a, "z": z0, "y": y0, "relu": True, "stats": stat(64)}
+        stem = {"tag": "stem", "conv": conv, "bn": bn, "x": a, "z": z0, "y": y0, "relu": True, "res": False, "stats": stat(64)}
         self._bn_train(z0, bn, True, None, dev, st, out=y0, save=stem["stats"])
         Hq, Wq = (Ho - 1) // 2 + 1, (Wo - 1) // 2 + 1
         cur = self._act("pool", N, Hq, Wq, 64, 1, dev)
@@ -1436,9 +1437,11 @@ class ResNetPlan:
                 dz = self._act((u["tag"], "dz"), N, xin.H, xin.W, C, 1, dev)
                 strides = (dz.img_stride, s * dz.row_stride, s * dz.px_stride, dz.interior_off())
             dg, db = torch.empty_like(bn.weight, dtype=torch.float32), torch.empty_like(bn.bias, dtype=torch.float32)
-            check(L_.yolo_batchnorm_bwd(dy.p, dy.halo, y.p if u["relu"] else None, y.halo, z.p, z.halo, N, z.H, z.W, C, ptr(bn.weight.detach()),
-                                        ptr(u["stats"]), dz.p, strides[0], strides[1], strides[2], strides[3], 1 if store_masked else 0,
-                                        ptr(dg), ptr(db), ptr(acc), ptr(self._coef), st), f"batchnorm_bwd {u['tag']}")
+            from_z = u["relu"] and not u["res"]        # conv -> BN -> ReLU: the mask is recomputed from z, y is not read
+            check(L_.yolo_batchnorm_bwd(dy.p, dy.halo, y.p if (u["relu"] and not from_z) else None, y.halo, z.p, z.halo, N, z.H, z.W, C,
+                                        ptr(bn.weight.detach()), ptr(u["stats"]), dz.p, strides[0], strides[1], strides[2], strides[3],
+                                        1 if store_masked else 0, 1 if from_z else 0, ptr(dg), ptr(db), ptr(acc), ptr(self._coef), st),
+                  f"batchnorm_bwd {u['tag']}")
             grads[bn.weight], grads[bn.bias] = dg, db
             return dz
 
