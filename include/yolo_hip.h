@@ -147,6 +147,9 @@ typedef struct yolo_igemm_desc {
                                workgroups start (slot % skew_phases) * skew_step shader cycles late, so that the CUs
                                do not all reach their output stores at the same moment (0 = off)                  */
     int32_t skew_step;
+    void *bn_stats;         /* != NULL (bf16 output, no split_k / pool2 / pixel range): YOLO_BN_ACC_REPLICAS * 2*Cout doubles into
+                               which the launch adds, per output channel, the sum and the sum of squares of the values it
+                               stored -- the statistics pass of a following yolo_batchnorm_train_fwd (stats_ready = 1) */
 } yolo_igemm_desc;
 
 #define YOLO_EPI_NONE 0        /* out = acc                                                        */
@@ -370,8 +373,10 @@ int yolo_batchnorm_train_fwd(void *z_bf16, int N, int H, int W, int C, int halo,
                              double eps, double momentum, float *running_mean, float *running_var,
                              const void *residual_bf16, int residual_halo, int relu, double *acc2c,
                              float *scale_shift, void *out_bf16, int out_halo, float *save_mean_invstd,
-                             yolo_stream_t stream);
-/* (out_bf16 != NULL: the result goes to that buffer [N][H+2*out_halo][W+2*out_halo][C] and z is kept -- a trainable
+                             int stats_ready, yolo_stream_t stream);
+/* (stats_ready = 1: acc2c already holds the sums -- the producing yolo_igemm accumulated them (yolo_igemm_desc.bn_stats) --
+ *  and the statistics pass over z is skipped;
+ *  out_bf16 != NULL: the result goes to that buffer [N][H+2*out_halo][W+2*out_halo][C] and z is kept -- a trainable
  *  trunk needs z for the backward pass; save_mean_invstd != NULL: 4*C floats -- batch mean, 1/sqrt(var + eps), and the
  *  scale / shift the forward applied, y = fma(z, scale, shift).)
  *

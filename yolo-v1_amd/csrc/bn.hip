@@ -302,7 +302,7 @@ using namespace yolo;
 
 YOLO_API int yolo_batchnorm_train_fwd(void *z, int N, int H, int W, int C, int halo, const float *gamma, const float *beta, double eps, double momentum,
                                       float *running_mean, float *running_var, const void *residual, int residual_halo, int relu, double *acc2c,
-                                      float *scale_shift, void *out, int out_halo, float *save_mean_invstd, yolo_stream_t stream)
+                                      float *scale_shift, void *out, int out_halo, float *save_mean_invstd, int stats_ready, yolo_stream_t stream)
 {
     if (!z || !gamma || !beta || !acc2c || !scale_shift || N <= 0 || H <= 0 || W <= 0 || C <= 0 || halo < 0 || residual_halo < 0 || out_halo < 0)
         return fail(YOLO_E_ARG, "yolo_batchnorm_train_fwd: bad argument");
@@ -314,8 +314,10 @@ YOLO_API int yolo_batchnorm_train_fwd(void *z, int N, int H, int W, int C, int h
     long gy = (P + (long)ppb * 32 - 1) / ((long)ppb * 32);     // ~32 pixels per thread
     if (gy > 2048) gy = 2048;
     if (gy < 1) gy = 1;
-    hipLaunchKernelGGL(bn_stats_kernel, dim3((C8 + gpb - 1) / gpb, (unsigned)gy), dim3(256), 0, s, (const bf16_t *)z, N, H, W, C, halo, acc2c);
-    if (int rc = check_launch("yolo_batchnorm_train_fwd(stats)")) return rc;
+    if (!stats_ready) {
+        hipLaunchKernelGGL(bn_stats_kernel, dim3((C8 + gpb - 1) / gpb, (unsigned)gy), dim3(256), 0, s, (const bf16_t *)z, N, H, W, C, halo, acc2c);
+        if (int rc = check_launch("yolo_batchnorm_train_fwd(stats)")) return rc;
+    }
     hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, s, acc2c, C, (double)P, gamma, beta, eps, momentum, running_mean, running_var, scale_shift,
                        scale_shift + C, save_mean_invstd);
     if (int rc = check_launch("yolo_batchnorm_train_fwd(finalize)")) return rc;

@@ -63,6 +63,7 @@ struct IgemmParams {
     int px_fastest;         // tile order inside an XCD's contiguous range: 1 = pixel tiles fastest (one weight panel per XCD)
     int skew_phases;        // > 1: first-round workgroups start skew_cycles * phase late (see yolo_igemm)
     long skew_cycles;
+    double *stats;          // != nullptr: per-channel sum / sum of squares of the (bf16-rounded) outputs, see yolo_igemm_desc.bn_stats
 };
 
 #define GLDS16(gptr, lptr) \
@@ -96,7 +97,8 @@ struct IgemmCfg {
     static constexpr int PPX = TPX / WPX;                    // pixels per epilogue pass (one wave column)
     static constexpr int EPI_BYTES = PPX * EP * 4;
     static constexpr int TABLE_BYTES = TPX * 32;             // per pixel: in_base, out_base, aux_base (int64 each, padded to 4)
-    static constexpr int MAIN_BYTES = (NST * STAGE_BYTES > EPI_BYTES) ? NST * STAGE_BYTES : EPI_BYTES;
+    static constexpr int RED_BYTES = WCO * WPX * 64 * 16 * 4;   // per-thread BatchNorm partial sums (bn_stats), behind the epilogue slab
+    static constexpr int MAIN_BYTES = (NST * STAGE_BYTES > EPI_BYTES + RED_BYTES) ? NST * STAGE_BYTES : EPI_BYTES + RED_BYTES;
     static constexpr int LDS_BYTES = TABLE_BYTES + MAIN_BYTES;
     static constexpr int A_INSTR = A_BYTES / 1024 / NW;      // glds wave-instructions per wave per stage
     static constexpr int B_INSTR = B_BYTES / 1024 / NW;
@@ -108,7 +110,9 @@ struct IgemmCfg {
     static_assert(TPX <= NTHR, "one table entry per thread");
 };
 
-template <int TCO, int TPX, int BK, int WCO, int WPX, int NST, int MF>
+// STATS: the epilogue also accumulates BatchNorm's per-channel sums (yolo_igemm_desc.bn_stats) -- a separate instantiation,
+// so that the kernels of the plain path keep their exact code and register count
+template <int TCO, int TPX, int BK, int WCO, int WPX, int NST, int MF, bool STATS>
 __global__ void __launch_bounds__(WCO * WPX * 64, 2) igemm_kernel(const IgemmParams p)
 {
     using Cfg = IgemmCfg<TCO, TPX, BK, WCO, WPX, NST, MF>;
@@ -414,6 +418,13 @@ __global__ void __launch_bounds__(WCO * WPX * 64, 2) igemm_kernel(const IgemmPar
 #pragma unroll
     for (int k = 0; k < 8; ++k) bias8[k] = has_bias && (co + k < p.Cout) ? p.bias[co + k] : 0.0f;
     const bool split = gridDim.y > 1;
+    // BatchNorm statistics of this thread's outputs (p.stats) live in LDS behind the epilogue slab, not in registers: the
+    // accumulators of the later passes are still live here and the 256x128 staggered kernel has none to spare
+    float *red = reinterpret_cast<float *>(stage_base + Cfg::EPI_BYTES) + tid * 16;
+    if constexpr (STATS) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) red[k] = 0.0f;
+    }
 
     for (int q = 0; q < WPX; ++q) {
         if (q > 0) __syncthreads();   // the previous slab has been streamed out
@@ -553,18 +564,43 @@ __global__ void __launch_bounds__(WCO * WPX * 64, 2) igemm_kernel(const IgemmPar
                 pk.z = (unsigned)f32_to_bf16(v[4]) | ((unsigned)f32_to_bf16(v[5]) << 16);
                 pk.w = (unsigned)f32_to_bf16(v[6]) | ((unsigned)f32_to_bf16(v[7]) << 16);
                 *reinterpret_cast<uint4 *>(o) = pk;  // Cout % 8 == 0 is required for bf16 outputs
+                if constexpr (STATS) {
+                    const unsigned w4[4] = {pk.x, pk.y, pk.z, pk.w};
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        const float r = __uint_as_float((k & 1) ? (w4[k >> 1] & 0xffff0000u) : (w4[k >> 1] << 16));   // the value as stored
+                        red[k] += r;
+                        red[8 + k] += r * r;
+                    }
+                }
+            }
+        }
+    }
+    if constexpr (STATS) {
+        // fold the threads that share a channel chunk (tid % CCH) through LDS, then one fp64 atomic pair per channel and tile
+        // into one of YOLO_BN_ACC_REPLICAS accumulators (same-address fp64 atomics serialise)
+        __syncthreads();
+        const float *all = reinterpret_cast<const float *>(stage_base + Cfg::EPI_BYTES);
+        for (int c = tid; c < TCO; c += NTHR) {
+            const int c8 = c >> 3, k = c & 7;
+            float a = 0.0f, b = 0.0f;
+            for (int j = 0; j < NTHR / CCH; ++j) { a += all[(j * CCH + c8) * 16 + k]; b += all[(j * CCH + c8) * 16 + 8 + k]; }
+            if (co0 + c < p.Cout) {
+                double *rep = p.stats + (size_t)(blockIdx.x % YOLO_BN_ACC_REPLICAS) * 2 * p.Cout;
+                atomicAdd(rep + co0 + c, (double)a);
+                atomicAdd(rep + p.Cout + co0 + c, (double)b);
             }
         }
     }
 }
 
-template <int TCO, int TPX, int BK, int WCO, int WPX, int NST, int MF = MFMA_32x32x16>
-static int launch(const IgemmParams &p, int splits, hipStream_t s)
+template <int TCO, int TPX, int BK, int WCO, int WPX, int NST, int MF, bool STATS>
+static int launch_impl(const IgemmParams &p, int splits, hipStream_t s)
 {
     using Cfg = IgemmCfg<TCO, TPX, BK, WCO, WPX, NST, MF>;
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&igemm_kernel<TCO, TPX, BK, WCO, WPX, NST, MF>), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&igemm_kernel<TCO, TPX, BK, WCO, WPX, NST, MF, STATS>), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
         if (e != hipSuccess) return fail((int)e, "yolo_igemm: hipFuncSetAttribute(%d B LDS): %s", Cfg::LDS_BYTES, hipGetErrorString(e));
         attr_done = true;
     }
@@ -584,8 +620,14 @@ static int launch(const IgemmParams &p, int splits, hipStream_t s)
     if (p.px_fastest < 0) q.px_fastest = 0;   // measured: channel-tiles-fastest is never slower on this network (tile_order overrides)
     q.nk_per_split = (q.nk + splits - 1) / splits;
     const int real_splits = (q.nk + q.nk_per_split - 1) / q.nk_per_split;
-    hipLaunchKernelGGL((igemm_kernel<TCO, TPX, BK, WCO, WPX, NST, MF>), dim3(q.n_co_tiles * q.n_px_tiles, real_splits), dim3(Cfg::NTHR), Cfg::LDS_BYTES, s, q);
+    hipLaunchKernelGGL((igemm_kernel<TCO, TPX, BK, WCO, WPX, NST, MF, STATS>), dim3(q.n_co_tiles * q.n_px_tiles, real_splits), dim3(Cfg::NTHR), Cfg::LDS_BYTES, s, q);
     return check_launch("yolo_igemm");
+}
+
+template <int TCO, int TPX, int BK, int WCO, int WPX, int NST, int MF = MFMA_32x32x16>
+static int launch(const IgemmParams &p, int splits, hipStream_t s)
+{
+    return p.stats ? launch_impl<TCO, TPX, BK, WCO, WPX, NST, MF, true>(p, splits, s) : launch_impl<TCO, TPX, BK, WCO, WPX, NST, MF, false>(p, splits, s);
 }
 
 // Finishing pass of a split-K conv: acc fp32 [M][Cout] (dense, summed by the split workgroups' atomics) -> the layer's
@@ -674,6 +716,9 @@ YOLO_API int yolo_igemm(const yolo_igemm_desc *d, const void *in, const void *w,
     if (d->skew_phases < 0 || d->skew_phases > 64 || d->skew_step < 0 || d->skew_step > (1 << 22)) return fail(YOLO_E_ARG, "yolo_igemm: skew_phases %d / skew_step %d", d->skew_phases, d->skew_step);
     p.skew_phases = d->skew_phases;
     p.skew_cycles = d->skew_step;
+    p.stats = (double *)d->bn_stats;
+    if (p.stats && (d->out_fp32 || splits > 1 || d->pool2 || d->px_begin || d->px_end))
+        return fail(YOLO_E_UNSUPPORTED, "yolo_igemm: bn_stats needs a plain bf16 launch (no split_k, pool2, pixel range)");
     p.pool = d->pool2 == 2 ? 2 : (d->pool2 ? 1 : 0);
     if (p.pool == 2 && !aux) return fail(YOLO_E_ARG, "yolo_igemm: pool2 = 2 writes the un-pooled activation through aux (pointer + aux_* strides)");
     p.pool_tw = 16;

@@ -40,6 +40,7 @@ class IgemmDesc(ctypes.Structure):
         ("tile_hint", ctypes.c_int32),
         ("px_begin", ctypes.c_int64), ("px_end", ctypes.c_int64),
         ("skew_phases", ctypes.c_int32), ("skew_step", ctypes.c_int32),
+        ("bn_stats", ctypes.c_void_p),
     ]
 
 
@@ -93,7 +94,7 @@ _SIGS = {
     "yolo_decode_gt": [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p],
     "yolo_nms": [c_void_p, c_void_p, c_int, c_int, c_double, c_int, c_void_p, c_void_p, c_void_p],
     "yolo_batchnorm_train_fwd": [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_double, c_double, c_void_p, c_void_p, c_void_p, c_int,
-                                 c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p],
+                                 c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p],
     "yolo_batchnorm_bwd": [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, ctypes.c_long, ctypes.c_long,
                            ctypes.c_long, ctypes.c_long, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
     "yolo_map_match": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, ctypes.POINTER(c_double), c_int, c_double, c_double, c_double,

@@ -37,6 +37,7 @@ def _round_up(a: int, b: int) -> int:
 TIMERS: list | None = None
 # tests / tuning: force a tile configuration of yolo_igemm (0 = library heuristic, see yolo_igemm_desc.tile_hint)
 TILE_HINT = 0
+BN_STATS_IN_CONV = True      # ResNet trunk in batch-statistics mode: BatchNorm's sums come out of the conv's epilogue (yolo_igemm_desc.bn_stats)
 IGEMM_LAUNCHES = 0  # yolo_igemm launches so far (bench.py: launches per step of the dominant kernel)
 STEM_KERNEL = True  # 7x7/s2 stem through yolo_conv_stem7_fwd (False: the generic row-segment implicit GEMM; tests compare)
 STEM_POOL_BWD_FUSED = True  # backward of the pool + LeakyReLU behind the stem inside yolo_wgrad_stem7_pooled (False: separate pass)
@@ -95,6 +96,9 @@ _TAIL_CANDIDATES = (5, 3, 4)
 def _run_plan_igemm(L_, d: IgemmDesc, plan, inp, w, bias, aux, out, st, what):
     """plan = (hint, order) | (hint, order, px_cut, tail_hint): the second form runs pixels [0, px_cut) with the large
     tile `hint` -- whole rounds of the chip -- and the rest with the small tile `tail_hint` in one short round."""
+    if d.bn_stats and (plan[0] == "splitk" or len(plan) == 4):
+        # a launch that also accumulates BatchNorm statistics must be one plain launch: keep the plan's main configuration
+        plan = (plan[1], 1) if plan[0] == "splitk" else (plan[0], plan[1])
     if plan[0] == "splitk":
         # ("splitk", hint, S): few-pixel deep-K layer -- S workgroups per output tile, fp32 atomics into a dense scratch,
         # then the epilogue as a separate pass (yolo_igemm_finish)
@@ -141,6 +145,7 @@ def igemm_call(d: IgemmDesc, inp, w, bias, aux, out, st, what: str):
     best = _TUNED.get(key)
     if best is None and AUTOTUNE and TIMERS is None and d.N * d.Ho * d.Wo >= 2048:
         dev = torch.device("cuda", torch.cuda.current_device())
+        stats_ptr, d.bn_stats = d.bn_stats, None        # tuning repeats the launch: keep it idempotent
 
         def timed(plan):
             try:
@@ -212,6 +217,7 @@ def igemm_call(d: IgemmDesc, inp, w, bias, aux, out, st, what: str):
                     times[("splitk", c, 2)] = t
         best = min(times, key=times.get) if times else (0, 0)
         _TUNED[key] = best
+        d.bn_stats = stats_ptr
     if best is None:
         best = (0, 0)
     _run_plan_igemm(L_, d, best, inp, w, bias, aux, out, st, what)
@@ -1200,12 +1206,11 @@ class ResNetPlan:
         self._raw = (ver, out)
         return out
 
-    def _bn_train(self, a: Act, bn: nn.BatchNorm2d, relu: bool, residual: Act | None, dev, st, out: Act | None = None, save: torch.Tensor | None = None):
+    def _bn_train(self, a: Act, bn: nn.BatchNorm2d, relu: bool, residual: Act | None, dev, st, out: Act | None = None, save: torch.Tensor | None = None,
+                  stats_ready: bool = False):
         """BatchNorm with batch statistics (+ residual, + ReLU) in place on the conv output, running statistics updated."""
         C = a.C
-        if self._bn_scratch is None or self._bn_scratch[0].device != dev:
-            self._bn_scratch = (torch.zeros(_hip.BN_ACC_REPLICAS * 2 * 2048, dtype=torch.float64, device=dev), torch.empty(2 * 2048, dtype=torch.float32, device=dev))
-        acc, ss = self._bn_scratch
+        acc, ss = self._scratch(dev)
         if C > 2048 or bn.weight is None or not bn.track_running_stats:
             raise NotImplementedError("batch-statistics BatchNorm: affine layers with running statistics and C <= 2048")
         mom = 0.1 if bn.momentum is None else bn.momentum
@@ -1213,8 +1218,13 @@ class ResNetPlan:
                                              ptr(bn.running_mean), ptr(bn.running_var), residual.p if residual is not None else None,
                                              residual.halo if residual is not None else 0, 1 if relu else 0, ptr(acc), ptr(ss),
                                              out.p if out is not None else None, out.halo if out is not None else 0,
-                                             ptr(save) if save is not None else None, st), "batchnorm_train_fwd")
+                                             ptr(save) if save is not None else None, 1 if stats_ready else 0, st), "batchnorm_train_fwd")
         bn.num_batches_tracked += 1
+
+    def _scratch(self, dev):
+        if self._bn_scratch is None or self._bn_scratch[0].device != dev:
+            self._bn_scratch = (torch.zeros(_hip.BN_ACC_REPLICAS * 2 * 2048, dtype=torch.float64, device=dev), torch.empty(2 * 2048, dtype=torch.float32, device=dev))
+        return self._bn_scratch
 
     def _conv_bn_train(self, tag, a_in: Act, packed, N, relu: bool, residual: Act | None, dev, st):
         wf, _, conv, bn = packed
@@ -1228,9 +1238,10 @@ class ResNetPlan:
         d.stride, d.KH, d.KW, d.tap_len, d.Cout = s, k, k, conv.in_channels, conv.out_channels
         d.out_img_stride, d.out_row_stride, d.out_px_stride, d.out_off = a_out.img_stride, a_out.row_stride, a_out.px_stride, a_out.interior_off()
         d.epilogue, d.slope = EPI_NONE, 1.0
+        d.bn_stats = self._scratch(dev)[0].data_ptr() if BN_STATS_IN_CONV else None      # the conv's epilogue accumulates BatchNorm's sums
         with _timed(str(tag), "igemm", 2.0 * N * Ho * Wo * conv.out_channels * conv.in_channels * k * k):
             igemm_call(d, a_in.p, ptr(wf), None, None, a_out.p, st, f"igemm {tag}")
-        self._bn_train(a_out, bn, relu, residual, dev, st)
+        self._bn_train(a_out, bn, relu, residual, dev, st, stats_ready=BN_STATS_IN_CONV)
         return a_out
 
     def forward_batch_stats(self, x: torch.Tensor) -> torch.Tensor:
@@ -1330,9 +1341,10 @@ class ResNetPlan:
         d.stride, d.KH, d.KW, d.tap_len, d.Cout = s, k, k, conv.in_channels, conv.out_channels
         d.out_img_stride, d.out_row_stride, d.out_px_stride, d.out_off = z.img_stride, z.row_stride, z.px_stride, z.interior_off()
         d.epilogue, d.slope = EPI_NONE, 1.0
+        d.bn_stats = self._scratch(dev)[0].data_ptr() if BN_STATS_IN_CONV else None      # the conv's epilogue accumulates BatchNorm's sums
         with _timed(str(tag), "igemm", 2.0 * N * Ho * Wo * conv.out_channels * conv.in_channels * k * k):
             igemm_call(d, a_in.p, ptr(wf), None, None, z.p, st, f"igemm {tag}")
-        self._bn_train(z, bn, relu, residual, dev, st, out=y, save=stats)
+        self._bn_train(z, bn, relu, residual, dev, st, out=y, save=stats, stats_ready=BN_STATS_IN_CONV)
         return {"tag": tag, "conv": conv, "bn": bn, "x": a_in, "z": z, "y": y, "relu": relu, "res": residual is not None, "stats": stats, "wd": wd,
                 "k": k, "s": s, "p": p}
 
