@@ -1568,7 +1568,7 @@ class ResNetPlan:
         else:
             d.epilogue = EPI_BIAS_LRELU if relu else EPI_BIAS
         with _timed(str(tag), "igemm", 2.0 * N * Ho * Wo * conv.out_channels * conv.in_channels * k * k):
-            _igemm(lib(), d, a_in.p, ptr(wf), ptr(b), aux, a_out.p, st, f"igemm {tag}")
+            igemm_call(d, a_in.p, ptr(wf), ptr(b), aux, a_out.p, st, f"igemm {tag}")
         return a_out
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
