@@ -276,6 +276,7 @@ def main():
         from yolo.optim import Adam as HipAdam
         tm = YOLOv1(backbone=ResNetBackbone(pretrained=False, freeze=False)).to(dev).train()
         topt = HipAdam(tm.parameters(), lr=1e-4, weight_decay=5e-4, max_grad_norm=10.0)
+        topt.attach_plan(tm.head.hip_plan())
         tcrit = YOLOLoss()
 
         def rstep():

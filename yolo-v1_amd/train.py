@@ -80,6 +80,8 @@ def main():
         optimizer = Adam(params, lr=a.lr, weight_decay=a.weight_decay, max_grad_norm=10.0)
         if model._fusable():
             optimizer.attach_plan(model.hip_plan())
+        elif hasattr(model.head, "hip_plan"):          # DetectionHead on a ResNet trunk: its Linear layers' bf16 operands
+            optimizer.attach_plan(model.head.hip_plan())
     else:
         optimizer = torch.optim.Adam(params, lr=a.lr, weight_decay=a.weight_decay)
     scheduler = torch.optim.lr_scheduler.MultiStepLR(optimizer, milestones=[int(e) for e in a.lr_decay_epochs.split(",")], gamma=0.1)
