@@ -41,3 +41,19 @@ for splits in (8, 16, 24, 32, 48):
     d.slope, d.out_fp32, d.epilogue, d.split_k = 0.1, 1, EPI_NONE, splits
     ms = timeit(lambda: check(lib().yolo_igemm(ctypes.byref(d), ptr(x), ptr(w), None, None, ptr(acc), stream())))
     print(f"fc1 forward (plain [O][K] weights) split_k {splits}: {ms:.4f} ms  {O * K * 2 / ms / 1e6:.0f} GB/s")
+
+# blocked weight panels (the layout the engine uses for inference): [ceil(O/128)][K/64][128][64]
+wf32 = w.float()
+panels = torch.empty(((O + 127) // 128) * (K // 64) * 128 * 64, dtype=torch.bfloat16, device=dev)
+check(lib().yolo_pack_fc_weight_blocked(ptr(wf32), O, K, ptr(panels), stream()))
+del wf32
+for hint in (0, 3, 4):
+    for splits in (24, 48, 96):
+        d = IgemmDesc()
+        d.N, d.Ho, d.Wo = N, 1, 1
+        d.in_img_stride, d.in_row_stride, d.in_px_stride, d.in_off = K, 0, K, 0
+        d.stride, d.KH, d.KW, d.tap_len, d.Cout = 1, 1, 1, K, O
+        d.out_img_stride, d.out_row_stride, d.out_px_stride, d.out_off = O, 0, O, 0
+        d.slope, d.out_fp32, d.epilogue, d.split_k, d.w_blocked, d.tile_hint = 0.1, 1, EPI_NONE, splits, 1, hint
+        ms = timeit(lambda: check(lib().yolo_igemm(ctypes.byref(d), ptr(x), ptr(panels), None, None, ptr(acc), stream())))
+        print(f"fc1 forward (blocked panels) hint {hint} split_k {splits}: {ms:.4f} ms  {O * K * 2 / ms / 1e6:.0f} GB/s")

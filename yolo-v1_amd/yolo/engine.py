@@ -684,7 +684,8 @@ class Plan:
                 d.w_blocked = 0 if train else 1
                 last = (li == len(self.layers) - 1)
                 nk = K // 64
-                splits = max(1, min(48, nk // 16)) if K >= 4096 else 1
+                # blocked panels (inference) run the 3-stage weight-stream kernel: 32 co-tiles x 32 splits = two full rounds of 512 slots
+                splits = max(1, min(32 if d.w_blocked else 48, nk // 16)) if K >= 4096 else 1
                 b = L.bias.detach()
                 if splits > 1:
                     acc = torch.zeros((N, L.Cout), dtype=torch.float32, device=dev)
