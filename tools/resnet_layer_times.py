@@ -5,6 +5,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "yolo-v1_amd"))
 import torch
 from yolo import YOLOv1, ResNetBackbone, engine
+engine.TILE_HINT = int(os.environ.get("TILE_HINT", "0"))
 m = YOLOv1(backbone=ResNetBackbone(pretrained=False, freeze=True)).cuda().eval()
 x = torch.randn(64, 3, 448, 448, device="cuda")
 with torch.no_grad():
