@@ -138,7 +138,9 @@ typedef struct yolo_igemm_desc {
     int32_t tile_order;     /* 0 = heuristic; 1 = channel tiles fastest; 2 = pixel tiles fastest inside an XCD's range   */
     int32_t tile_hint;      /* 0 = let the library pick the tile configuration; 1: 128x128, 2: 256x128
                                (8 waves, 3 stages), 3: 128x64, 4: 64x128, 5/6: 1/2 on the 16x16x32
-                               MFMA shape  (tuning / tests)                                        */
+                               MFMA shape, 11: 256x128x64 and 12: 256x256x32 / 13: 256x128x32 with the staggered
+                               two-phase schedule (8 waves), 7-10: BK = 32 variants of 64x128  (tuning / tests;
+                               a caller that wants the best plan times them per problem, as engine.igemm_call does) */
     int64_t px_begin, px_end; /* compute only output pixels [px_begin, px_end) of the flattened (n, oy, ox) index
                                (0, 0 = all).  Lets a caller run the bulk of a layer with a large tile in whole
                                rounds of the 256 CUs and the remainder with a small tile in one short round,
