@@ -38,3 +38,4 @@ for _ in range(steps):
     step()
 torch.cuda.synchronize()
 print(f"{1e3 * (time.perf_counter() - t0) / steps:.3f} ms/step over {steps} steps (+3 warm-up)")
+print(f"peak device memory {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB")
