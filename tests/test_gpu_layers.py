@@ -363,7 +363,7 @@ def test_fc_dgrad_behind_flatten_matches_cpu():
         _close(a, b, 3.0, n, frac=0.01)
 
 
-@pytest.mark.parametrize("hint", [1, 2, 3, 4, 5, 6, 11, 12, 13])
+@pytest.mark.parametrize("hint", [1, 2, 3, 4, 5, 6, 10, 11, 12, 13])
 def test_every_tile_configuration(hint):
     """the same 3x3 / 1x1 chain through each yolo_igemm tile configuration (128x128, 256x128 8-wave
     3-stage ring, 128x64, 64x128), forward and data-gradient, with ragged pixel and channel tiles."""

@@ -745,6 +745,7 @@ YOLO_API int yolo_igemm(const yolo_igemm_desc *d, const void *in, const void *w,
     }
     if (force == 12) return launch<256, 256, 32, 2, 4, 4, MFMA_16x16x32_STAGGER>(p, splits, s);
     if (force == 13) return launch<256, 128, 32, 4, 2, 4, MFMA_16x16x32_STAGGER>(p, splits, s);
+    if (force == 10) return launch<64, 128, 32, 2, 2, 2>(p, splits, s);     // 28 KB of LDS: five workgroups per CU (thin-K 1x1 layers)
     if (!bk64) {
         if (force == 7) return launch<64, 128, 32, 2, 2, 3>(p, splits, s);
         if (force == 9) return launch<64, 128, 32, 2, 2, 4>(p, splits, s);

@@ -89,7 +89,7 @@ def _flush_caches(dev):
 
 
 # tile edge (co, px) of the configurations the tuner may combine
-_TILE = {1: (128, 128), 3: (128, 64), 4: (64, 128), 5: (128, 128), 11: (256, 128), 12: (256, 256), 13: (256, 128)}
+_TILE = {1: (128, 128), 3: (128, 64), 4: (64, 128), 5: (128, 128), 10: (64, 128), 11: (256, 128), 12: (256, 256), 13: (256, 128)}
 _TAIL_CANDIDATES = (5, 3, 4)
 
 
@@ -164,6 +164,8 @@ def igemm_call(d: IgemmDesc, inp, w, bias, aux, out, st, what: str):
                 return None
 
         cands = [c for c in _TUNE_CANDIDATES if not (d.pool2 and c in (3, 12))]
+        if d.KH == 1 and d.KW == 1 and d.tap_len <= 256 and not d.pool2:
+            cands.append(10)      # thin-K 1x1 layers stream: 64x128x32, 28 KB of LDS, five workgroups per CU
         orders = (1, 2) if (d.Cout * d.KH * d.KW * d.tap_len * 2 > (4 << 20) and d.Cout >= 1024) else (1,)
         times = {}
         for c in cands:
