@@ -37,6 +37,11 @@ typedef void *yolo_stream_t;
 
 int yolo_hip_abi_version(void);
 const char *yolo_hip_last_error(void);
+/* Diagnostics (libyolo_hip_diag.so, `make diag`, -DIGEMM_STAMPS): the staggered yolo_igemm configurations write eight
+ * s_memtime stamps of K iteration `k_iter` per wave of the first 512 workgroups to buf[(workgroup * 8 + wave) * 8 + i]
+ * (int64, device memory of 512 * 64 entries; NULL switches it off).  The product library compiles no stamps and returns
+ * YOLO_E_UNSUPPORTED for a non-NULL buffer.  tools/stamps_igemm.py reads them. */
+int yolo_debug_stamps(void *buf, int k_iter);
 
 /* ---------------------------------------------------------------------------------------------
  * Post-processing: S x S x B box decode, pairwise IoU, per-image NMS.  fp64 arithmetic on fp32
@@ -139,7 +144,8 @@ typedef struct yolo_igemm_desc {
     int32_t tile_hint;      /* 0 = let the library pick the tile configuration; 1: 128x128, 2: 256x128
                                (8 waves, 3 stages), 3: 128x64, 4: 64x128, 5/6: 1/2 on the 16x16x32
                                MFMA shape, 11: 256x128x64 and 12: 256x256x32 / 13: 256x128x32 with the staggered
-                               two-phase schedule (8 waves), 7-10: BK = 32 variants of 64x128  (tuning / tests;
+                               two-phase schedule (8 waves), 14: 256 x 208 x 32 staggered with an uneven 7 / 6 column
+                               split between the wave groups (see tile_px), 7-10: BK = 32 variants of 64x128  (tuning / tests;
                                a caller that wants the best plan times them per problem, as engine.igemm_call does) */
     int64_t px_begin, px_end; /* compute only output pixels [px_begin, px_end) of the flattened (n, oy, ox) index
                                (0, 0 = all).  Lets a caller run the bulk of a layer with a large tile in whole
@@ -152,6 +158,15 @@ typedef struct yolo_igemm_desc {
     void *bn_stats;         /* != NULL (bf16 output, no split_k / pool2 / pixel range): YOLO_BN_ACC_REPLICAS * 2*Cout doubles into
                                which the launch adds, per output channel, the sum and the sum of squares of the values it
                                stored -- the statistics pass of a following yolo_batchnorm_train_fwd (stats_ready = 1) */
+    int32_t tile_px;        /* > 0: a workgroup's tile covers only tile_px pixels of the flattened (n, oy, ox) index (at most the
+                               configuration's pixel-tile edge; its remaining slots idle).  The layers of this network have
+                               N * 49 * 4^k output pixels, which never divide into whole rounds of 256 CUs with 128- or 256-pixel
+                               tiles; tile_hint 14 (256 channels x 208 pixel slots, uneven staggered split) with tile_px = 196
+                               gives 64 * 4^k tiles per channel tile -- whole rounds at batch 64.  0 = all slots         */
+    int32_t split_slabs;    /* split_k > 1 only.  1: split s STORES its partial tile into slab s of `out` = fp32
+                               [split_k][N*Ho*Wo][Cout] (no zero fill, no atomics) and yolo_igemm_finish adds the slabs in
+                               the fixed order 0, 1, .. -- bit-reproducible for any split count.  0: fp32 atomics into one
+                               zero-filled [N*Ho*Wo][Cout] buffer                                                       */
 } yolo_igemm_desc;
 
 #define YOLO_EPI_NONE 0        /* out = acc                                                        */
@@ -168,8 +183,10 @@ int yolo_igemm(const yolo_igemm_desc *d, const void *in_bf16, const void *w_bf16
                const float *bias, const void *aux_bf16, void *out, yolo_stream_t stream);
 /* Finishing pass of a split-K convolution.  Few-pixel, deep-K layers (the 7x7x1024 ones: 3136 pixels at batch 64,
  * K = 9216) have too few output tiles to fill 256 CUs; the caller runs yolo_igemm with split_k > 1, out_fp32 = 1,
- * YOLO_EPI_NONE into a zero-filled dense fp32 [N*Ho*Wo][Cout] buffer and then this pass, with the layer's REAL
- * descriptor (epilogue, out_* / aux_* strides), applies bias / LeakyReLU / LeakyReLU'(aux) and writes bf16. */
+ * YOLO_EPI_NONE into a zero-filled dense fp32 [N*Ho*Wo][Cout] buffer (or, with split_slabs = 1, into split_k slabs of
+ * that shape) and then this pass, with the layer's REAL descriptor (epilogue, out_* / aux_* strides; split_k = the number
+ * of slabs to add in fixed order when split_slabs = 1, else ignored), applies bias / LeakyReLU / LeakyReLU'(aux) and
+ * writes bf16. */
 int yolo_igemm_finish(const yolo_igemm_desc *d, const float *acc, const float *bias, const void *aux_bf16,
                       void *out_bf16, yolo_stream_t stream);
 

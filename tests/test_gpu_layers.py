@@ -363,11 +363,13 @@ def test_fc_dgrad_behind_flatten_matches_cpu():
         _close(a, b, 3.0, n, frac=0.01)
 
 
-@pytest.mark.parametrize("hint", [1, 2, 3, 4, 5, 6, 10, 11, 12, 13])
+@pytest.mark.parametrize("hint", [1, 2, 3, 4, 5, 6, 10, 11, 12, 13, 14, (14, 196), (14, 49), (12, 196), (5, 98)])
 def test_every_tile_configuration(hint):
     """the same 3x3 / 1x1 chain through each yolo_igemm tile configuration (128x128, 256x128 8-wave
-    3-stage ring, 128x64, 64x128), forward and data-gradient, with ragged pixel and channel tiles."""
+    3-stage ring, 128x64, 64x128, 256x208 with the uneven staggered split), forward and data-gradient, with ragged pixel
+    and channel tiles; (hint, tile_px) also limits the pixels per tile (yolo_igemm_desc.tile_px)."""
     from yolo import engine
+    hint, engine.TILE_PX = hint if isinstance(hint, tuple) else (hint, 0)
     torch.manual_seed(4)
     mods = nn.Sequential(
         nn.Conv2d(64, 256, 3, 1, 1), nn.LeakyReLU(0.1),
@@ -379,7 +381,7 @@ def test_every_tile_configuration(hint):
     try:
         yc, yg, gc, gg = _run_both(mods, x, gy)
     finally:
-        engine.TILE_HINT = 0
+        engine.TILE_HINT, engine.TILE_PX = 0, 0
     _close(yg, yc, 6.0, f"hint {hint} y")
     for i, (a, b) in enumerate(zip(gg, gc)):
         _close(a, b, 12.0, f"hint {hint} grad {i}", frac=0.01)
@@ -420,6 +422,20 @@ def test_pixel_range_launches_tile_the_output_exactly():
         assert torch.equal(mixed.view(-1, 256)[:1280], ref.view(-1, 256)[:1280])
         sk = run(("splitk", hint if hint != 12 else 3, 3))     # split-K + finishing pass: fp32 atomics, so not bit-identical
         _close(sk.permute(0, 3, 1, 2), ref.permute(0, 3, 1, 2).float(), 2.0, f"split-K vs hint {hint}")
+        # split-K into slabs + fixed-order reduce: within rounding of the single launch and bit-reproducible run to run
+        for S in (2, 4):
+            sl = run(("slabs", hint, S, 0))
+            _close(sl.permute(0, 3, 1, 2), ref.permute(0, 3, 1, 2).float(), 2.0, f"slabs {S} vs hint {hint}")
+            for _ in range(3):
+                assert torch.equal(run(("slabs", hint, S, 0)), sl), (hint, S)
+    # tiles limited to tile_px pixels (hint 14: uneven staggered split) against the plain 128x128 launch
+    ref = run((5, 1))
+    for pl in (("tile", 14, 1, 0), ("tile", 14, 1, 196), ("tile", 14, 1, 100), ("tile", 12, 1, 196), ("tile", 14, 1, 196, 3, 4000),
+               ("slabs", 14, 3, 196)):
+        got = run(pl)
+        _close(got.permute(0, 3, 1, 2), ref.permute(0, 3, 1, 2).float(), 2.0, f"plan {pl}")
+        assert torch.equal(run(pl), got), pl
+    assert torch.equal(run(("tile", 14, 1, 196)), run(("tile", 14, 1, 0)))    # same K order per output: bit-identical
     d.px_begin, d.px_end = 10, 5
     assert lib().yolo_igemm(ctypes.byref(d), a_in.p, ptr(wf), ptr(L.bias.detach()), None, a_out.p, stream()) != 0
     plan._release(key, ws)

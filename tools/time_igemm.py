@@ -9,7 +9,11 @@ from yolo._hip import lib, check, ptr, stream, IgemmDesc, EPI_BIAS_LRELU
 from yolo.engine import Act
 
 N = int(os.environ.get("N", 64))
-hints = [int(h) for h in os.environ.get("HINTS", "0,1,2,3,4").split(",")]
+# HINTS entries: tile_hint [+ 100 * tile_order] [":" tile_px], e.g. "5,12,14:196"
+def _parse(h):
+    a, _, b = h.partition(":")
+    return (int(a), int(b or 0))
+hints = [_parse(h) for h in os.environ.get("HINTS", "0,1,2,3,4").split(",")]
 dev = torch.device("cuda")
 h = 448
 tot = {k: 0.0 for k in hints}
@@ -47,8 +51,9 @@ for item in synth.YOLOV1_BACKBONE_CFG:
     # warm the clocks up on this problem, then time every configuration in three interleaved rounds and keep the
     # minimum: the first configuration measured after an idle gap otherwise reads 10-20 % slow
     def run(hint, reps):
-        d.tile_hint = hint % 100
-        d.tile_order = hint // 100
+        d.tile_hint = hint[0] % 100
+        d.tile_order = hint[0] // 100
+        d.tile_px = hint[1]
         for _ in range(reps):
             check(lib().yolo_igemm(ctypes.byref(d), x.p, ptr(w), ptr(b), None, y.p, stream()))
     ok = []
@@ -75,9 +80,9 @@ for item in synth.YOLOV1_BACKBONE_CFG:
     for hint in hints:
         if hint in best:
             tot[hint] += best[hint]
-            line += f" h{hint}: {best[hint]:6.3f} ms {fl/best[hint]/1e9:6.0f} TF |"
+            line += f" h{hint[0]}:{hint[1]} {best[hint]:6.3f} ms {fl/best[hint]/1e9:6.0f} TF |"
         else:
-            line += f" h{hint}: n/a |"
+            line += f" h{hint[0]}:{hint[1]} n/a |"
     print(line)
     del x, y
-print("totals (ms):", {k: round(v, 3) for k, v in tot.items()})
+print("totals (ms):", {f"{k[0]}:{k[1]}": round(v, 3) for k, v in tot.items()})

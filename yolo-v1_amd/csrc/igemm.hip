@@ -33,7 +33,10 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
-enum { MFMA_32x32x16 = 0, MFMA_16x16x32 = 1, MFMA_16x16x32_STAGGER = 2 };
+// MFMA_16x16x32_STAGGER_U: the staggered schedule with an UNEVEN pixel split between its two wave groups -- a tile of
+// TPX = 16 * NTILES pixels with NTILES odd (208 = 13 x 16): group A owns the first (NTILES + 1) / 2 pixel tiles, group B the
+// rest.  Both groups sit pairwise on the same SIMDs, so every SIMD still sees the same number of MFMAs per K step.
+enum { MFMA_32x32x16 = 0, MFMA_16x16x32 = 1, MFMA_16x16x32_STAGGER = 2, MFMA_16x16x32_STAGGER_U = 3 };
 
 struct IgemmParams {
     const bf16_t *in;
@@ -60,9 +63,14 @@ struct IgemmParams {
     int nk_per_split;
     int n_co_tiles, n_px_tiles;
     long px_begin;          // first output pixel of this launch (pixel-range launches: see yolo_igemm_desc.px_begin)
+    int tpx_valid;          // pixels of the flattened index per tile (<= TPX; the remaining slots of a tile idle): yolo_igemm_desc.tile_px
+    long slab_stride;       // split-K: > 0 = split y stores its partial tile densely at out + y * slab_stride (fixed-order reduce
+                            // in yolo_igemm_finish, deterministic); 0 = fp32 atomics into out
     int px_fastest;         // tile order inside an XCD's contiguous range: 1 = pixel tiles fastest (one weight panel per XCD)
     int skew_phases;        // > 1: first-round workgroups start skew_cycles * phase late (see yolo_igemm)
     long skew_cycles;
+    long *dbg;              // diagnostic builds (-DIGEMM_STAMPS) only: s_memtime stamps of K iteration dbg_it, see yolo_debug_stamps
+    int dbg_it;
     double *stats;          // != nullptr: per-channel sum / sum of squares of the (bf16-rounded) outputs, see yolo_igemm_desc.bn_stats
 };
 
@@ -104,11 +112,16 @@ template <int TCO, int TPX, int BK, int WCO, int WPX, int NST, int MF = MFMA_32x
 struct IgemmCfg {
     static constexpr int NW = WCO * WPX;                     // waves per workgroup
     static constexpr int NTHR = NW * 64;
+    static constexpr bool UNEVEN = MF == MFMA_16x16x32_STAGGER_U;
     static constexpr int A_BYTES = TCO * BK * 2;
-    static constexpr int B_BYTES = TPX * BK * 2;
+    // the B stage is rounded up to whole 1-KB pieces per wave (TPX = 208: 13 KB -> 16 KB at BK = 32); the pad rows are
+    // loaded from one fixed address and never read
+    static constexpr int B_BYTES = (TPX * BK * 2 + 1024 * NW - 1) / (1024 * NW) * (1024 * NW);
     static constexpr int STAGE_BYTES = A_BYTES + B_BYTES;
     static constexpr int EP = TCO + 4;                       // fp32 epilogue row pitch (floats)
-    static constexpr int PPX = TPX / WPX;                    // pixels per epilogue pass (one wave column)
+    static constexpr int NTILES = TPX / 16;                  // 16-pixel MFMA columns of the tile (uneven split)
+    static constexpr int NT0 = (NTILES + 1) / 2, NT1 = NTILES / 2;
+    static constexpr int PPX = UNEVEN ? NT0 * 16 : TPX / WPX;   // pixels per epilogue pass (one wave column)
     static constexpr int EPI_BYTES = PPX * EP * 4;
     static constexpr int TABLE_BYTES = TPX * 32;             // per pixel: in_base, out_base, aux_base (int64 each, padded to 4)
     static constexpr int RED_BYTES = WCO * WPX * 64 * 16 * 4;   // per-thread BatchNorm partial sums (bn_stats), behind the epilogue slab
@@ -119,8 +132,10 @@ struct IgemmCfg {
     static constexpr int LOADS = A_INSTR + B_INSTR;
     static constexpr int FR = MF != MFMA_32x32x16 ? 16 : 32;        // MFMA tile edge
     static constexpr int KS = MF != MFMA_32x32x16 ? 32 : 16;        // K per MFMA
-    static constexpr int MT = TCO / WCO / FR, NT = TPX / WPX / FR;  // MFMA tiles per wave
+    static constexpr int MT = TCO / WCO / FR, NT = UNEVEN ? NT0 : TPX / WPX / FR;  // MFMA tiles per wave (uneven: of group A)
     static_assert(A_BYTES % (1024 * NW) == 0 && B_BYTES % (1024 * NW) == 0, "stage must split evenly over the waves");
+    static_assert(!UNEVEN || (WPX == 2 && TPX % 16 == 0), "uneven split: two pixel groups of 16-pixel columns");
+    static_assert(UNEVEN || TPX * BK * 2 == B_BYTES, "only the uneven configuration pads its B stage");
     static_assert(TPX <= NTHR, "one table entry per thread");
 };
 
@@ -131,7 +146,8 @@ __global__ void __launch_bounds__(WCO * WPX * 64, 2) igemm_kernel(const IgemmPar
 {
     using Cfg = IgemmCfg<TCO, TPX, BK, WCO, WPX, NST, MF>;
     constexpr bool M16 = MF != MFMA_32x32x16;
-    constexpr bool STG = MF == MFMA_16x16x32_STAGGER;
+    constexpr bool UNEVEN = Cfg::UNEVEN;
+    constexpr bool STG = MF == MFMA_16x16x32_STAGGER || UNEVEN;
     constexpr int FR = Cfg::FR;
     constexpr int MT = Cfg::MT, NT = Cfg::NT, NW = Cfg::NW, NTHR = Cfg::NTHR;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -141,7 +157,9 @@ __global__ void __launch_bounds__(WCO * WPX * 64, 2) igemm_kernel(const IgemmPar
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wco = wave / WPX, wpx = wave % WPX;
+    // uneven split: the pixel group IS the stagger group (waves 0..3 = A = pixel columns [0, NT0), waves 4..7 = B)
+    const int wco = UNEVEN ? wave % WCO : wave / WPX, wpx = UNEVEN ? wave / WCO : wave % WPX;
+    const int px_lo = UNEVEN ? wpx * Cfg::NT0 * 16 : wpx * (TPX / WPX);   // first tile pixel of this wave's column
 
     // ---- start skew (8-wave configurations: one workgroup per CU).  With equal tiles every CU reaches its prologue
     // burst and its output stores at the same moment and the memory system serves 256 identical phases at once.
@@ -167,7 +185,8 @@ __global__ void __launch_bounds__(WCO * WPX * 64, 2) igemm_kernel(const IgemmPar
     const int co_tile = p.px_fastest ? bid / p.n_px_tiles : bid % p.n_co_tiles;
     const int px_tile = p.px_fastest ? bid % p.n_px_tiles : bid / p.n_co_tiles;
     const int co0 = co_tile * TCO;
-    const long px0 = p.px_begin + (long)px_tile * TPX;
+    const int tpv = p.tpx_valid;           // pixels per tile (TPX unless the launch asked for fewer: tile_px)
+    const long px0 = p.px_begin + (long)px_tile * tpv;
 
     // ---- per-pixel address tables (input row base / output base), one pixel per thread.
     // Normal mode: tile = TPX consecutive pixels of the flattened (n, oy, ox) index.
@@ -187,7 +206,7 @@ __global__ void __launch_bounds__(WCO * WPX * 64, 2) igemm_kernel(const IgemmPar
             if (!valid) { oy = 0; ox = 0; }
         } else {
             long m = px0 + tid;
-            valid = m < p.M;
+            valid = m < p.M && tid < tpv;
             if (!valid) m = p.M - 1;
             n = (int)(m / p.HoWo);
             const int rem = (int)(m - (long)n * p.HoWo);
@@ -224,7 +243,7 @@ __global__ void __launch_bounds__(WCO * WPX * 64, 2) igemm_kernel(const IgemmPar
             const int pos = q * 64 + lane;
             const int R = pos >> 4, s = (pos & 15) ^ swz_key<BK, M16>(R);
             const int r = R * RPB + s / CPR, chunk = s % CPR;
-            b_src[i] = p.in + tab[4 * r] + chunk * 8;
+            b_src[i] = r < TPX ? p.in + tab[4 * r] + chunk * 8 : p.in + tab[0];   // pad rows of the B stage: one line, never read
             b_dst[i] = Cfg::A_BYTES + q * 1024;
         }
     }
@@ -270,7 +289,11 @@ __global__ void __launch_bounds__(WCO * WPX * 64, 2) igemm_kernel(const IgemmPar
 #pragma unroll
     for (int i = 0; i < MT; ++i) a_rd[i] = lds_off<BK, M16>(wco * (TCO / WCO) + i * FR + (lane & (FR - 1)), M16 ? (lane >> 4) : (lane >> 5));
 #pragma unroll
-    for (int i = 0; i < NT; ++i) b_rd[i] = Cfg::A_BYTES + lds_off<BK, M16>(wpx * (TPX / WPX) + i * FR + (lane & (FR - 1)), M16 ? (lane >> 4) : (lane >> 5));
+    for (int i = 0; i < NT; ++i) {
+        int row = px_lo + i * FR + (lane & (FR - 1));
+        if (UNEVEN && row >= TPX) row = TPX - 1;          // group B has one column fewer: its last slot is never used
+        b_rd[i] = Cfg::A_BYTES + lds_off<BK, M16>(row, M16 ? (lane >> 4) : (lane >> 5));
+    }
 
     typedef typename std::conditional<M16, f32x4, f32x16>::type acc_t;
     acc_t acc[MT][NT];
@@ -287,23 +310,25 @@ __global__ void __launch_bounds__(WCO * WPX * 64, 2) igemm_kernel(const IgemmPar
     // that everyone has finished reading the stage that is overwritten next.
     constexpr int KSTEPS = BK / Cfg::KS;
     constexpr int KSH = M16 ? 6 : 5;   // the k-step only touches chunk-index bits that the row part left clear -> XOR
-    auto read_frags = [&](int buf, bf16x8(&af)[KSTEPS][MT], bf16x8(&bfr)[KSTEPS][NT]) {
+    auto read_frags = [&](int buf, bf16x8(&af)[KSTEPS][MT], bf16x8(&bfr)[KSTEPS][NT], auto ntc) {
+        constexpr int NTG = decltype(ntc)::value;      // pixel columns of this wave group (NT, or NT1 for group B of an uneven split)
         const char *sb = stage_base + buf * Cfg::STAGE_BYTES;
 #pragma unroll
         for (int ks = 0; ks < KSTEPS; ++ks) {
 #pragma unroll
             for (int i = 0; i < MT; ++i) af[ks][i] = *reinterpret_cast<const bf16x8 *>(sb + (a_rd[i] ^ (ks << KSH)));
 #pragma unroll
-            for (int j = 0; j < NT; ++j) bfr[ks][j] = *reinterpret_cast<const bf16x8 *>(sb + (b_rd[j] ^ (ks << KSH)));
+            for (int j = 0; j < NTG; ++j) bfr[ks][j] = *reinterpret_cast<const bf16x8 *>(sb + (b_rd[j] ^ (ks << KSH)));
         }
     };
-    auto mfmas = [&](bf16x8(&af)[KSTEPS][MT], bf16x8(&bfr)[KSTEPS][NT]) {
+    auto mfmas = [&](bf16x8(&af)[KSTEPS][MT], bf16x8(&bfr)[KSTEPS][NT], auto ntc) {
+        constexpr int NTG = decltype(ntc)::value;
 #pragma unroll
         for (int ks = 0; ks < KSTEPS; ++ks)
 #pragma unroll
             for (int i = 0; i < MT; ++i)
 #pragma unroll
-                for (int j = 0; j < NT; ++j) {
+                for (int j = 0; j < NTG; ++j) {
                     if constexpr (M16) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[ks][i], bfr[ks][j], acc[i][j], 0, 0, 0);
                     else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks][i], bfr[ks][j], acc[i][j], 0, 0, 0);
                 }
@@ -317,10 +342,12 @@ __global__ void __launch_bounds__(WCO * WPX * 64, 2) igemm_kernel(const IgemmPar
         //     slot:   0     1     2     3     4 ...
         //     A:      L0    M0    L1    M1    L2
         //     B:      -     L0    M0    L1    M1
-        // Global->LDS loads of stage s are issued by everybody in slot 2(s-2) (A in L, B in M) and each wave
+        // Global->LDS loads of stage s are issued in the L phases (A in slot 2(s-D), B in slot 2(s-D)+1) and each wave
         // drains its own part with a counted vmcnt at the end of slot 2s-1, one barrier before the first
-        // reader (A in slot 2s).  Buffer (s mod 3) was last read in slot 2(s-3)+1, two barriers earlier.
+        // reader (A in slot 2s).  Buffer (s mod NST) was last read in slot 2(s-NST)+1, at least one barrier earlier.
         static_assert(!STG || (NST >= 3 && NW == 8), "stagger needs 8 waves and a ring of >= 3 stages");
+        constexpr std::integral_constant<int, NT> ntA{};
+        constexpr std::integral_constant<int, UNEVEN ? Cfg::NT1 : NT> ntB{};
         // general ring of NST stages (D = NST-1 stages of distance): stage s is issued in slot 2(s-D), must
         // have landed by the end of slot 2s-1; at that wait D-1 younger stages may stay in flight.
         constexpr int D = NST - 1;
@@ -339,49 +366,81 @@ __global__ void __launch_bounds__(WCO * WPX * 64, 2) igemm_kernel(const IgemmPar
         __builtin_amdgcn_sched_barrier(0);
         bf16x8 af[KSTEPS][MT], bfr[KSTEPS][NT];
         int rd_buf = 0;
+#ifdef IGEMM_STAMPS
+        // diagnostic build: where one K iteration of this wave spends its cycles (stamps go to a buffer of their own)
+        long stamp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define STAMP(i) do { if (p.dbg && it == p.dbg_it) { __builtin_amdgcn_sched_barrier(0); stamp[i] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } } while (0)
+#else
+#define STAMP(i) do { } while (0)
+#endif
         if (!grpB) {
             int ld_buf = D % NST;
             for (int it = 0; it < nkk; ++it) {
-                read_frags(rd_buf, af, bfr);                                     // L(it)   (even slot)
+                STAMP(0);
+                read_frags(rd_buf, af, bfr, ntA);                                // L(it)   (even slot)
+                STAMP(1);
                 if (it + D < nkk) stage(ld_buf, kbeg + it + D);
+                STAMP(2);
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                STAMP(3);
                 __builtin_amdgcn_sched_barrier(0);
                 __builtin_amdgcn_s_barrier();
                 __builtin_amdgcn_sched_barrier(0);
+                STAMP(4);
                 __builtin_amdgcn_s_setprio(1);
-                mfmas(af, bfr);                                                  // M(it)   (odd slot)
+                mfmas(af, bfr, ntA);                                             // M(it)   (odd slot)
                 __builtin_amdgcn_s_setprio(0);
+                STAMP(5);
                 { const int left = nkk - 2 - it; wait_stage(left < 0 ? 0 : left); }   // stage it+1 landed
+                STAMP(6);
                 __builtin_amdgcn_sched_barrier(0);
                 __builtin_amdgcn_s_barrier();
                 __builtin_amdgcn_sched_barrier(0);
+                STAMP(7);
                 rd_buf = rd_buf + 1 == NST ? 0 : rd_buf + 1;
                 ld_buf = ld_buf + 1 == NST ? 0 : ld_buf + 1;
             }
             __builtin_amdgcn_s_barrier();
         } else {
-            if (D < nkk) stage(D % NST, kbeg + D);                               // slot 0
-            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_s_barrier();                                        // slot 0
             __builtin_amdgcn_sched_barrier(0);
-            int ld_buf = (D + 1) % NST;
+            int ld_buf = D % NST;
             for (int it = 0; it < nkk; ++it) {
-                read_frags(rd_buf, af, bfr);                                     // L(it)   (odd slot)
+                STAMP(0);
+                read_frags(rd_buf, af, bfr, ntB);                                // L(it)   (odd slot)
+                STAMP(1);
+                // the group's share of stage it+D is issued here, in the L phase (as group A does in its own): the MFMA pipe
+                // belongs to the partner wave now, and the M phase below stays pure MFMA (in-kernel stamps: ~390 cycles of
+                // DMA issue in front of the MFMAs left the pipe idle; tools/stamps_igemm.py)
+                if (it + D < nkk) stage(ld_buf, kbeg + it + D);
+                STAMP(2);
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 { const int left = nkk - 2 - it; wait_stage(left < 0 ? 0 : left); }   // stage it+1 landed
+                STAMP(3);
                 __builtin_amdgcn_sched_barrier(0);
                 __builtin_amdgcn_s_barrier();
                 __builtin_amdgcn_sched_barrier(0);
-                if (it + D + 1 < nkk) stage(ld_buf, kbeg + it + D + 1);          // M(it)   (even slot)
+                STAMP(4);
+                STAMP(5);
                 __builtin_amdgcn_s_setprio(1);
-                mfmas(af, bfr);
+                mfmas(af, bfr, ntB);                                             // M(it)   (even slot)
                 __builtin_amdgcn_s_setprio(0);
+                STAMP(6);
                 __builtin_amdgcn_sched_barrier(0);
                 __builtin_amdgcn_s_barrier();
                 __builtin_amdgcn_sched_barrier(0);
+                STAMP(7);
                 rd_buf = rd_buf + 1 == NST ? 0 : rd_buf + 1;
                 ld_buf = ld_buf + 1 == NST ? 0 : ld_buf + 1;
             }
         }
+#ifdef IGEMM_STAMPS
+        if (p.dbg && lane == 0 && blockIdx.x < 512) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) p.dbg[((long)blockIdx.x * 8 + wave) * 8 + i] = stamp[i];
+        }
+#endif
+#undef STAMP
     } else {
     constexpr int D = NST - 1;
 #pragma unroll
@@ -431,7 +490,9 @@ __global__ void __launch_bounds__(WCO * WPX * 64, 2) igemm_kernel(const IgemmPar
     float bias8[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) bias8[k] = has_bias && (co + k < p.Cout) ? p.bias[co + k] : 0.0f;
-    const bool split = gridDim.y > 1;
+    const bool split = gridDim.y > 1 && p.slab_stride == 0;
+    // split-K into slabs: split y owns the dense fp32 partial tile at out + y * slab_stride and takes the plain store path below
+    void *const outp = p.slab_stride ? (void *)(reinterpret_cast<float *>(p.out) + (long)blockIdx.y * p.slab_stride) : p.out;
     // BatchNorm statistics of this thread's outputs (p.stats) live in LDS behind the epilogue slab, not in registers: the
     // accumulators of the later passes are still live here and the 256x128 staggered kernel has none to spare
     float *red = reinterpret_cast<float *>(stage_base + Cfg::EPI_BYTES) + tid * 16;
@@ -465,12 +526,13 @@ __global__ void __launch_bounds__(WCO * WPX * 64, 2) igemm_kernel(const IgemmPar
         }
         __syncthreads();
         const int pbase = q * PPX;   // first tile pixel of this slab
+        const int ppx_q = UNEVEN && q == 1 ? Cfg::NT1 * 16 : PPX;   // its pixels (group B of an uneven split has one column fewer)
 
         if (split) {
             // split-K partial tile: fp32 atomics shaped as 256 contiguous bytes per wave-instruction (one
             // dword per lane along the channel axis) -- the fast form of global_atomic_add_f32
             float *o = reinterpret_cast<float *>(p.out);
-            for (int e = tid; e < PPX * TCO; e += NTHR) {
+            for (int e = tid; e < ppx_q * TCO; e += NTHR) {
                 const int lp = e / TCO, c = e - lp * TCO;
                 const long ob = tab[4 * (pbase + lp) + 1];
                 if (ob >= 0 && co0 + c < p.Cout) atomicAdd(o + ob + co0 + c, ep[lp * Cfg::EP + c]);
@@ -526,7 +588,7 @@ __global__ void __launch_bounds__(WCO * WPX * 64, 2) igemm_kernel(const IgemmPar
             continue;
         }
 #pragma unroll 2
-        for (int lp = tid / CCH; lp < PPX; lp += PX_PER_STEP) {
+        for (int lp = tid / CCH; lp < ppx_q; lp += PX_PER_STEP) {
             const int px = pbase + lp;
             const long ob = tab[4 * px + 1];
             if (ob < 0 || co >= p.Cout) continue;
@@ -561,7 +623,7 @@ __global__ void __launch_bounds__(WCO * WPX * 64, 2) igemm_kernel(const IgemmPar
                 }
             }
             if (p.out_fp32) {
-                float *o = reinterpret_cast<float *>(p.out) + ob + co;
+                float *o = reinterpret_cast<float *>(outp) + ob + co;
                 if (co + 8 <= p.Cout && ((ob + co) & 3) == 0) {
                     *reinterpret_cast<f32x4 *>(o) = f32x4{v[0], v[1], v[2], v[3]};
                     *reinterpret_cast<f32x4 *>(o + 4) = f32x4{v[4], v[5], v[6], v[7]};
@@ -612,20 +674,24 @@ template <int TCO, int TPX, int BK, int WCO, int WPX, int NST, int MF, bool STAT
 static int launch_impl(const IgemmParams &p, int splits, hipStream_t s)
 {
     using Cfg = IgemmCfg<TCO, TPX, BK, WCO, WPX, NST, MF>;
-    static bool attr_done = false;
-    if (!attr_done) {
+    static bool attr_done[64] = {};   // per device: a function's attributes belong to the device it is loaded on
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    if (!attr_done[dev]) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&igemm_kernel<TCO, TPX, BK, WCO, WPX, NST, MF, STATS>), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
         if (e != hipSuccess) return fail((int)e, "yolo_igemm: hipFuncSetAttribute(%d B LDS): %s", Cfg::LDS_BYTES, hipGetErrorString(e));
-        attr_done = true;
+        attr_done[dev] = true;
     }
     IgemmParams q = p;
     q.n_co_tiles = (p.Cout + TCO - 1) / TCO;
     if (p.pool) {
+        q.tpx_valid = TPX;
         q.pool_tiles_x = (p.Wo + p.pool_tw - 1) / p.pool_tw;
         q.pool_tiles_y = (p.HoWo / p.Wo + TPX / p.pool_tw - 1) / (TPX / p.pool_tw);
         q.n_px_tiles = (int)(p.M / p.HoWo) * q.pool_tiles_x * q.pool_tiles_y;
     } else {
-        q.n_px_tiles = (int)((p.M - p.px_begin + TPX - 1) / TPX);
+        if (q.tpx_valid <= 0 || q.tpx_valid > TPX) q.tpx_valid = TPX;
+        q.n_px_tiles = (int)((p.M - p.px_begin + q.tpx_valid - 1) / q.tpx_valid);
     }
     q.nk = (int)(p.Ktot / BK);
     // L2 working set: when the weights are much larger than an XCD's 4-MB L2, give each XCD its own weight
@@ -633,7 +699,8 @@ static int launch_impl(const IgemmParams &p, int splits, hipStream_t s)
     // weight tensor once per group of pixel tiles)
     if (p.px_fastest < 0) q.px_fastest = 0;   // measured: channel-tiles-fastest is never slower on this network (tile_order overrides)
     q.nk_per_split = (q.nk + splits - 1) / splits;
-    const int real_splits = (q.nk + q.nk_per_split - 1) / q.nk_per_split;
+    // slabs: every split must store its slab (the finishing pass adds all of them), also one whose K range is empty
+    const int real_splits = p.slab_stride ? splits : (q.nk + q.nk_per_split - 1) / q.nk_per_split;
     hipLaunchKernelGGL((igemm_kernel<TCO, TPX, BK, WCO, WPX, NST, MF, STATS>), dim3(q.n_co_tiles * q.n_px_tiles, real_splits), dim3(Cfg::NTHR), Cfg::LDS_BYTES, s, q);
     return check_launch("yolo_igemm");
 }
@@ -648,7 +715,7 @@ static int launch(const IgemmParams &p, int splits, hipStream_t s)
 // real output with the epilogue the un-split launch would have applied (bias / LeakyReLU / times LeakyReLU'(aux)),
 // bf16 into the zero-haloed NHWC buffer.  One thread = one pixel x 8 channels.
 __global__ void __launch_bounds__(256) igemm_finish_kernel(const float *__restrict__ acc, const float *__restrict__ bias, const bf16_t *__restrict__ aux,
-                                                           bf16_t *__restrict__ out, long M, int HoWo, int Wo, int Cout, int epilogue, float slope,
+                                                           bf16_t *__restrict__ out, long M, int slabs, int HoWo, int Wo, int Cout, int epilogue, float slope,
                                                            long out_img, int out_row, int out_px, int out_off, long aux_img, int aux_row, int aux_px, int aux_off)
 {
     const int C8 = Cout >> 3;
@@ -661,6 +728,12 @@ __global__ void __launch_bounds__(256) igemm_finish_kernel(const float *__restri
     const int oy = rem / Wo, ox = rem - oy * Wo;
     const float4 a = *reinterpret_cast<const float4 *>(acc + m * Cout + c), b = *reinterpret_cast<const float4 *>(acc + m * Cout + c + 4);
     float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    for (int sl = 1; sl < slabs; ++sl) {      // fixed order: the sum does not depend on which split finished first
+        const float *as = acc + (long)sl * M * Cout + m * Cout + c;
+        const float4 a2 = *reinterpret_cast<const float4 *>(as), b2 = *reinterpret_cast<const float4 *>(as + 4);
+        v[0] += a2.x; v[1] += a2.y; v[2] += a2.z; v[3] += a2.w;
+        v[4] += b2.x; v[5] += b2.y; v[6] += b2.z; v[7] += b2.w;
+    }
     if (epilogue == YOLO_EPI_BIAS || epilogue == YOLO_EPI_BIAS_LRELU) {
 #pragma unroll
         for (int k = 0; k < 8; ++k) v[k] += bias[c + k];
@@ -689,6 +762,20 @@ __global__ void __launch_bounds__(256) igemm_finish_kernel(const float *__restri
 
 using namespace yolo;
 
+static long *g_dbg = nullptr;
+static int g_dbg_it = 0;
+
+YOLO_API int yolo_debug_stamps(void *buf, int k_iter)
+{
+    g_dbg = (long *)buf;
+    g_dbg_it = k_iter;
+#ifdef IGEMM_STAMPS
+    return 0;
+#else
+    return buf ? fail(YOLO_E_UNSUPPORTED, "yolo_debug_stamps: this library was built without -DIGEMM_STAMPS (make diag)") : 0;
+#endif
+}
+
 YOLO_API int yolo_igemm(const yolo_igemm_desc *d, const void *in, const void *w, const float *bias, const void *aux, void *out, yolo_stream_t stream)
 {
     if (!d || !in || !w || !out) return fail(YOLO_E_ARG, "yolo_igemm: null pointer");
@@ -699,6 +786,10 @@ YOLO_API int yolo_igemm(const yolo_igemm_desc *d, const void *in, const void *w,
     if (d->epilogue < 0 || d->epilogue > YOLO_EPI_BIAS_ADD_LRELU) return fail(YOLO_E_ARG, "yolo_igemm: epilogue %d", d->epilogue);
     const int splits = d->split_k > 1 ? d->split_k : 1;
     if (splits > 1 && (!d->out_fp32 || d->epilogue != YOLO_EPI_NONE)) return fail(YOLO_E_ARG, "yolo_igemm: split_k needs fp32 output and EPI_NONE");
+    if (d->split_slabs && splits > 1 && (d->out_px_stride != d->Cout || d->out_off != 0 || d->out_row_stride != d->Wo * d->Cout
+                                         || d->out_img_stride != (int64_t)d->Ho * d->Wo * d->Cout))
+        return fail(YOLO_E_ARG, "yolo_igemm: split_slabs needs the dense [N*Ho*Wo][Cout] output addressing");
+    if (d->tile_px < 0) return fail(YOLO_E_ARG, "yolo_igemm: tile_px %d", d->tile_px);
     if (!d->out_fp32 && ((d->Cout & 7) || (d->out_off & 7) || (d->out_px_stride & 7) || (d->out_row_stride & 7) || (d->out_img_stride & 7)))
         return fail(YOLO_E_UNSUPPORTED, "yolo_igemm: bf16 output needs Cout and output strides in multiples of 8");
     if ((d->tap_len & 31) || (d->in_off & 7) || (d->in_px_stride & 3) || (d->in_row_stride & 7) || (d->in_img_stride & 7))
@@ -711,6 +802,8 @@ YOLO_API int yolo_igemm(const yolo_igemm_desc *d, const void *in, const void *w,
         return fail(YOLO_E_ARG, "yolo_igemm: bad pixel range [%ld, %ld) of %ld", (long)d->px_begin, (long)d->px_end, (long)p.M);
     if ((d->px_begin || d->px_end) && d->pool2) return fail(YOLO_E_UNSUPPORTED, "yolo_igemm: pixel ranges are not available with pool2");
     p.px_begin = d->px_begin;
+    p.tpx_valid = d->tile_px;     // clamped to the configuration's pixel-tile edge at launch
+    p.slab_stride = (d->split_slabs && splits > 1) ? (long)d->N * d->Ho * d->Wo * d->Cout : 0;
     if (d->px_end) p.M = d->px_end;   // the kernels bound pixels by p.M
     p.in_img_stride = d->in_img_stride; p.in_row_stride = d->in_row_stride; p.in_px_stride = d->in_px_stride; p.in_off = d->in_off; p.stride = d->stride;
     p.KH = d->KH; p.KW = d->KW; p.tap_len = d->tap_len; p.Cout = d->Cout;
@@ -731,11 +824,14 @@ YOLO_API int yolo_igemm(const yolo_igemm_desc *d, const void *in, const void *w,
     p.skew_phases = d->skew_phases;
     p.skew_cycles = d->skew_step;
     p.stats = (double *)d->bn_stats;
+    p.dbg = g_dbg;
+    p.dbg_it = g_dbg_it;
     if (p.stats && (d->out_fp32 || splits > 1 || d->pool2 || d->px_begin || d->px_end))
         return fail(YOLO_E_UNSUPPORTED, "yolo_igemm: bn_stats needs a plain bf16 launch (no split_k, pool2, pixel range)");
     p.pool = d->pool2 == 2 ? 2 : (d->pool2 ? 1 : 0);
     if (p.pool == 2 && !aux) return fail(YOLO_E_ARG, "yolo_igemm: pool2 = 2 writes the un-pooled activation through aux (pointer + aux_* strides)");
     p.pool_tw = 16;
+    if (p.pool && d->tile_px) return fail(YOLO_E_UNSUPPORTED, "yolo_igemm: tile_px is not available with pool2");
     if (p.pool && (splits > 1 || d->out_fp32 || (d->Ho & 1) || (d->Wo & 1) || (d->epilogue != YOLO_EPI_BIAS && d->epilogue != YOLO_EPI_BIAS_LRELU)))
         return fail(YOLO_E_UNSUPPORTED, "yolo_igemm: pool2 needs even Ho/Wo, bf16 output, a bias epilogue and no split-K");
     if (d->w_blocked) {
@@ -744,6 +840,10 @@ YOLO_API int yolo_igemm(const yolo_igemm_desc *d, const void *in, const void *w,
         return npx <= 64 ? launch<128, 64, 64, 2, 2, 3, MFMA_16x16x32>(p, splits, s) : launch<128, 128, 64, 2, 2, 2, MFMA_16x16x32>(p, splits, s);
     }
     if (force == 12) return launch<256, 256, 32, 2, 4, 4, MFMA_16x16x32_STAGGER>(p, splits, s);
+    if (force == 14) {
+        if (d->pool2) return fail(YOLO_E_UNSUPPORTED, "yolo_igemm: tile_hint 14 has no pooled epilogue");
+        return launch<256, 208, 32, 4, 2, 4, MFMA_16x16x32_STAGGER_U>(p, splits, s);
+    }
     if (force == 13) return launch<256, 128, 32, 4, 2, 4, MFMA_16x16x32_STAGGER>(p, splits, s);
     if (force == 10) return launch<64, 128, 32, 2, 2, 2>(p, splits, s);     // 28 KB of LDS: five workgroups per CU (thin-K 1x1 layers)
     if (!bk64) {
@@ -790,7 +890,7 @@ YOLO_API int yolo_igemm_finish(const yolo_igemm_desc *d, const float *acc, const
     const long M = (long)d->N * d->Ho * d->Wo;
     const long total = M * (d->Cout / 8);
     hipLaunchKernelGGL(igemm_finish_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, STRM(stream), acc, bias, (const bf16_t *)aux, (bf16_t *)out, M,
-                       d->Ho * d->Wo, d->Wo, d->Cout, d->epilogue, d->slope, (long)d->out_img_stride, d->out_row_stride, d->out_px_stride, d->out_off,
+                       (d->split_slabs && d->split_k > 1) ? d->split_k : 1, d->Ho * d->Wo, d->Wo, d->Cout, d->epilogue, d->slope, (long)d->out_img_stride, d->out_row_stride, d->out_px_stride, d->out_off,
                        (long)d->aux_img_stride, d->aux_row_stride, d->aux_px_stride, d->aux_off);
     return check_launch("yolo_igemm_finish");
 }

@@ -13,7 +13,8 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libyolo_hip.so")
+# YOLO_HIP_LIB: another build of the same library (tools: the stamped diagnostic build libyolo_hip_diag.so)
+LIB_PATH = os.environ.get("YOLO_HIP_LIB") or os.path.join(_HERE, "libyolo_hip.so")
 _LIB = None
 
 BN_ACC_REPLICAS = 16         # YOLO_BN_ACC_REPLICAS (include/yolo_hip.h)
@@ -41,6 +42,7 @@ class IgemmDesc(ctypes.Structure):
         ("px_begin", ctypes.c_int64), ("px_end", ctypes.c_int64),
         ("skew_phases", ctypes.c_int32), ("skew_step", ctypes.c_int32),
         ("bn_stats", ctypes.c_void_p),
+        ("tile_px", ctypes.c_int32), ("split_slabs", ctypes.c_int32),
     ]
 
 
@@ -90,6 +92,7 @@ NMS_INFERENCE, NMS_METRICS = 0, 1
 # name -> argtypes ; every symbol include/yolo_hip.h declares (tests check the list against the header)
 _SIGS = {
     "yolo_hip_abi_version": [],
+    "yolo_debug_stamps": [c_void_p, c_int],
     "yolo_decode": [c_void_p, c_int, c_int, c_int, c_int, c_double, c_void_p, c_void_p, c_void_p],
     "yolo_decode_gt": [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p],
     "yolo_nms": [c_void_p, c_void_p, c_int, c_int, c_double, c_int, c_void_p, c_void_p, c_void_p],
@@ -165,10 +168,17 @@ def lib():
     return _LIB
 
 
+E_ARG, E_UNSUPPORTED = -1, -2      # YOLO_E_ARG, YOLO_E_UNSUPPORTED (include/yolo_hip.h)
+
+
+class HipUnsupported(RuntimeError):
+    """the library refused a shape / configuration (YOLO_E_UNSUPPORTED) -- nothing was launched"""
+
+
 def check(rc: int, what: str = "") -> None:
     if rc != 0:
         msg = lib().yolo_hip_last_error().decode(errors="replace")
-        raise RuntimeError(f"libyolo_hip {what} failed (code {rc}): {msg}")
+        raise (HipUnsupported if rc == E_UNSUPPORTED else RuntimeError)(f"libyolo_hip {what} failed (code {rc}): {msg}")
 
 
 def ptr(t) -> c_void_p:
@@ -182,6 +192,37 @@ def stream() -> c_void_p:
 
 
 def require_cuda(*tensors) -> None:
+    dev = None
     for t in tensors:
-        if t is not None and not t.is_cuda:
+        if t is None:
+            continue
+        if not t.is_cuda:
             raise RuntimeError("libyolo_hip kernels need device tensors (got a CPU tensor)")
+        if dev is None:
+            dev = t.device
+        elif t.device != dev:
+            raise RuntimeError(f"libyolo_hip kernels need all tensors on one device (got {dev} and {t.device})")
+
+
+def device_guard(fn):
+    """Run ``fn`` with the CURRENT device set to the device of its tensor arguments.  The kernels are launched on
+    ``torch.cuda.current_stream()`` and scratch buffers are allocated on the current device, so a call with tensors on
+    ``cuda:1`` while the current device is 0 (``predict.py --device cuda:1``, ``YOLOInference(model, device=...)``) must
+    switch first; tensors on different devices are rejected."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapper(*args, **kw):
+        dev = None
+        for a in (*args, *kw.values()):
+            if isinstance(a, torch.Tensor) and a.is_cuda:
+                if dev is None:
+                    dev = a.device
+                elif a.device != dev:
+                    raise RuntimeError(f"{fn.__name__}: tensors on different devices ({dev} and {a.device})")
+        if dev is None or dev.index == torch.cuda.current_device():
+            return fn(*args, **kw)
+        with torch.cuda.device(dev):
+            return fn(*args, **kw)
+
+    return wrapper

@@ -18,6 +18,7 @@ Everything is enqueued on the current PyTorch stream; there is no host synchroni
 from __future__ import annotations
 
 import ctypes
+import os
 from dataclasses import dataclass, field
 
 import torch
@@ -37,6 +38,7 @@ def _round_up(a: int, b: int) -> int:
 TIMERS: list | None = None
 # tests / tuning: force a tile configuration of yolo_igemm (0 = library heuristic, see yolo_igemm_desc.tile_hint)
 TILE_HINT = 0
+TILE_PX = 0     # with TILE_HINT: yolo_igemm_desc.tile_px of the forced configuration
 BN_STATS_IN_CONV = True      # ResNet trunk in batch-statistics mode: BatchNorm's sums come out of the conv's epilogue (yolo_igemm_desc.bn_stats)
 IGEMM_LAUNCHES = 0  # yolo_igemm launches so far (bench.py: launches per step of the dominant kernel)
 STEM_KERNEL = True  # 7x7/s2 stem through yolo_conv_stem7_fwd (False: the generic row-segment implicit GEMM; tests compare)
@@ -69,14 +71,52 @@ class _timed:
         return False
 
 
-# ---- per-problem tile-configuration autotuning --------------------------------------------------------
-# The best yolo_igemm configuration depends on the layer shape (tile quantisation over 256 CUs, K depth) and
-# differs by < 15 % between candidates; on the first occurrence of a problem signature every candidate is timed
-# with events on the launch stream (min of 3 runs after a warm-up) and the winner is cached for the process.
-AUTOTUNE = True
+# ---- per-problem launch plans ---------------------------------------------------------------------------
+# The best yolo_igemm configuration depends on the layer shape (tile quantisation over 256 CUs, K depth).  Plans are DATA:
+# ``yolo/plans/gfx950.json`` ships the plans of every problem of the BASELINE configurations (measured once on MI355X by
+# tools/tune_plans.py) and is loaded at import, so every process and every rank runs the same launches -- outputs are
+# bit-identical across processes and nothing is timed, flushed or synchronised at run time.  A problem without an entry
+# takes ``_default_plan`` (a deterministic function of the shape).  AUTOTUNE = True (tools/tune_plans.py only) times the
+# candidates on first use and records the winner in _TUNED.
+#
+# plan forms (tuples; JSON lists):
+#   (hint, order)                          one launch of tile configuration `hint`
+#   (hint, order, px_cut, tail_hint)       pixels [0, px_cut) with `hint` (whole rounds of the chip), the rest with `tail_hint`
+#   ("skew", hint, order, phases, step)    one launch, first-round workgroups start phase * step cycles apart
+#   ("tile", hint, order, tile_px[, phases, step])   one launch whose tiles cover tile_px pixels (yolo_igemm_desc.tile_px)
+#   ("splitk", hint, S)                    S <= 2 K-splits with fp32 atomics into a zeroed scratch + yolo_igemm_finish
+#   ("slabs", hint, S, tile_px)            S K-splits stored as slabs + fixed-order reduce in yolo_igemm_finish (deterministic)
+AUTOTUNE = False
 _TUNE_CANDIDATES = (5, 11, 12, 3, 4)      # 128x128 | 256x128 staggered | 256x256 staggered | 128x64 | 64x128
 _TUNED: dict = {}
 _FLUSH = None
+PLAN_FILE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "plans", "gfx950.json")
+
+
+def _key_str(key) -> str:
+    return ",".join(str(int(v)) for v in key)
+
+
+def load_plans(path: str = PLAN_FILE) -> int:
+    """merge the plans of a JSON file ({"<key>": [plan...]}) into _TUNED; returns the number of entries read"""
+    import json
+    if not os.path.exists(path):
+        return 0
+    with open(path) as f:
+        data = json.load(f)
+    for k, v in data.get("plans", {}).items():
+        _TUNED[tuple(int(t) for t in k.split(","))] = tuple(v)
+    return len(data.get("plans", {}))
+
+
+def save_plans(path: str = PLAN_FILE, note: str = "") -> None:
+    import json
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    body = {"arch": "gfx950", "key": "N,Ho,Wo,KH,KW,tap_len,Cout,stride,epilogue,pool2,out_px_stride,in_px_stride", "note": note,
+            "plans": {_key_str(k): list(v) for k, v in sorted(_TUNED.items())}}
+    with open(path, "w") as f:
+        json.dump(body, f, indent=0, separators=(",", ":"))
+        f.write("\n")
 
 
 def _flush_caches(dev):
@@ -88,42 +128,89 @@ def _flush_caches(dev):
     _FLUSH.fill_(1)
 
 
-# tile edge (co, px) of the configurations the tuner may combine
-_TILE = {1: (128, 128), 3: (128, 64), 4: (64, 128), 5: (128, 128), 10: (64, 128), 11: (256, 128), 12: (256, 256), 13: (256, 128)}
+# tile edge (co, px slots) of the configurations the tuner may combine
+_TILE = {1: (128, 128), 3: (128, 64), 4: (64, 128), 5: (128, 128), 10: (64, 128), 11: (256, 128), 12: (256, 256), 13: (256, 128), 14: (256, 208)}
 _TAIL_CANDIDATES = (5, 3, 4)
+# (workgroup slots of the chip, relative time of one tile) per configuration, for _default_plan: 8-wave configurations run
+# one workgroup per CU, the 4-wave ones two; times are relative to a 256x256 tile and follow the measured in-tile rates
+_TILE_COST = {12: (256, 1.00), 14: (256, 0.84), 11: (256, 0.54), 5: (512, 0.36), 3: (512, 0.20), 4: (512, 0.20)}
+
+_SPLITK_SCRATCH: dict = {}
+
+
+def _splitk_scratch(n: int, zero: bool) -> torch.Tensor:
+    """fp32 scratch of n elements on the current device for a split-K launch (allocated once per device and grown on
+    demand; the atomics form needs it zero-filled, the slab form does not)"""
+    dev = torch.cuda.current_device()
+    buf = _SPLITK_SCRATCH.get(dev)
+    if buf is None or buf.numel() < n:
+        buf = _SPLITK_SCRATCH[dev] = torch.empty(n, dtype=torch.float32, device=torch.device("cuda", dev))
+    v = buf[:n]
+    if zero:
+        v.zero_()
+    return v
+
+
+def _default_plan(d: IgemmDesc):
+    """launch plan of a problem without a measured entry: the configuration with the smallest predicted time =
+    rounds over the chip's workgroup slots x relative tile time (deterministic, no timing)."""
+    M = d.N * d.Ho * d.Wo
+    if M < 2048 or d.pool2:
+        return (0, 0)
+    best, best_t = (0, 0), None
+    for hint, (slots, cost) in _TILE_COST.items():
+        tco, tpx = _TILE[hint]
+        forms = [((hint, 1), tpx)]
+        if hint == 14:
+            forms = [(("tile", 14, 1, 196), 196)] if M % 196 == 0 else [(("tile", 14, 1, 208), 208)]
+        for plan, px in forms:
+            tiles = ((d.Cout + tco - 1) // tco) * ((M + px - 1) // px)
+            t = ((tiles + slots - 1) // slots) * cost
+            if best_t is None or t < best_t - 1e-9:
+                best, best_t = plan, t
+    return best
 
 
 def _run_plan_igemm(L_, d: IgemmDesc, plan, inp, w, bias, aux, out, st, what):
-    """plan = (hint, order) | (hint, order, px_cut, tail_hint): the second form runs pixels [0, px_cut) with the large
-    tile `hint` -- whole rounds of the chip -- and the rest with the small tile `tail_hint` in one short round."""
-    if d.bn_stats and (plan[0] == "splitk" or len(plan) == 4):
+    """run one yolo_igemm problem with a launch plan (forms: see above)"""
+    if d.bn_stats and (plan[0] in ("splitk", "slabs") or (isinstance(plan[0], int) and len(plan) == 4)):
         # a launch that also accumulates BatchNorm statistics must be one plain launch: keep the plan's main configuration
-        plan = (plan[1], 1) if plan[0] == "splitk" else (plan[0], plan[1])
-    if plan[0] == "splitk":
-        # ("splitk", hint, S): few-pixel deep-K layer -- S workgroups per output tile, fp32 atomics into a dense scratch,
+        plan = (plan[1], 1) if plan[0] in ("splitk", "slabs") else (plan[0], plan[1])
+    d.tile_px, d.px_begin, d.px_end, d.skew_phases, d.skew_step = 0, 0, 0, 0, 0
+    if plan[0] in ("splitk", "slabs"):
+        # few-pixel deep-K layer: S workgroups per output tile into a dense fp32 scratch (atomics, or one slab per split),
         # then the epilogue as a separate pass (yolo_igemm_finish)
+        slabs = plan[0] == "slabs"
+        S = plan[2]
         M = d.N * d.Ho * d.Wo
-        acc = torch.zeros((M, d.Cout), dtype=torch.float32, device=torch.device("cuda", torch.cuda.current_device()))
+        acc = _splitk_scratch(M * d.Cout * (S if slabs else 1), zero=not slabs)
         d2 = IgemmDesc.from_buffer_copy(d)
-        d2.out_fp32, d2.epilogue, d2.split_k, d2.tile_hint, d2.tile_order = 1, EPI_NONE, plan[2], plan[1], 1
+        d2.out_fp32, d2.epilogue, d2.split_k, d2.tile_hint, d2.tile_order = 1, EPI_NONE, S, plan[1], 1
         d2.out_img_stride, d2.out_row_stride, d2.out_px_stride, d2.out_off = d.Ho * d.Wo * d.Cout, d.Wo * d.Cout, d.Cout, 0
-        d2.px_begin, d2.px_end = 0, 0
+        d2.split_slabs, d2.tile_px = (1, plan[3]) if slabs else (0, 0)
         _igemm(L_, d2, inp, w, None, None, ptr(acc), st, what)
-        check(L_.yolo_igemm_finish(ctypes.byref(d), ptr(acc), bias, aux, out, st), what + " (finish)")
+        d.split_k, d.split_slabs = (S, 1) if slabs else (1, 0)
+        try:
+            check(L_.yolo_igemm_finish(ctypes.byref(d), ptr(acc), bias, aux, out, st), what + " (finish)")
+        finally:
+            d.split_k, d.split_slabs = 1, 0
         return
-    if plan[0] == "skew":
-        # ("skew", hint, order, phases, step): one launch of an 8-wave configuration whose first-round workgroups start
-        # phase * step cycles apart (yolo_igemm_desc.skew_phases)
-        d.tile_hint, d.tile_order, d.skew_phases, d.skew_step = plan[1], plan[2], plan[3], plan[4]
-        d.px_begin, d.px_end = 0, 0
+    if plan[0] in ("skew", "tile"):
+        # one launch of an 8-wave configuration: ("skew", hint, order, phases, step) staggers the first-round workgroups
+        # (yolo_igemm_desc.skew_phases); ("tile", hint, order, tile_px[, phases, step]) sets the pixels per tile as well
+        if plan[0] == "skew":
+            d.tile_hint, d.tile_order, d.skew_phases, d.skew_step = plan[1], plan[2], plan[3], plan[4]
+        else:
+            d.tile_hint, d.tile_order, d.tile_px = plan[1], plan[2], plan[3]
+            if len(plan) > 4:
+                d.skew_phases, d.skew_step = plan[4], plan[5]
         try:
             _igemm(L_, d, inp, w, bias, aux, out, st, what)
         finally:
-            d.skew_phases, d.skew_step = 0, 0
+            d.skew_phases, d.skew_step, d.tile_px = 0, 0, 0
         return
     d.tile_hint, d.tile_order = plan[0], plan[1]
     if len(plan) == 2:
-        d.px_begin, d.px_end = 0, 0
         _igemm(L_, d, inp, w, bias, aux, out, st, what)
         return
     d.px_begin, d.px_end = 0, plan[2]
@@ -133,100 +220,121 @@ def _run_plan_igemm(L_, d: IgemmDesc, plan, inp, w, bias, aux, out, st, what):
     d.px_begin, d.px_end = 0, 0
 
 
+def _tune(L_, d: IgemmDesc, inp, w, bias, aux, out, st, what):
+    """time the candidate plans of one problem (events on the launch stream behind a cache flush, min of 3) and return the
+    fastest.  Only reached with AUTOTUNE = True (tools/tune_plans.py)."""
+    dev = torch.device("cuda", torch.cuda.current_device())
+    stats_ptr, d.bn_stats = d.bn_stats, None        # tuning repeats the launch: keep it idempotent
+    M = d.N * d.Ho * d.Wo
+
+    def timed(plan):
+        try:
+            _run_plan_igemm(L_, d, plan, inp, w, bias, aux, out, st, what)
+        except _hip.HipUnsupported:
+            return None          # this configuration does not take the shape; every other error is a real failure
+        ts = []
+        for _ in range(3):
+            _flush_caches(dev)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            _run_plan_igemm(L_, d, plan, inp, w, bias, aux, out, st, what)
+            e1.record()
+            e1.synchronize()
+            ts.append(e0.elapsed_time(e1))
+        return min(ts)
+
+    times = {}
+
+    def consider(plan):
+        t = timed(plan)
+        if t is not None:
+            times[plan] = t
+
+    cands = [c for c in _TUNE_CANDIDATES if not (d.pool2 and c in (3, 12))]
+    if d.KH == 1 and d.KW == 1 and d.tap_len <= 256 and not d.pool2:
+        cands.append(10)      # thin-K 1x1 layers stream: 64x128x32, 28 KB of LDS, five workgroups per CU
+    orders = (1, 2) if (d.Cout * d.KH * d.KW * d.tap_len * 2 > (4 << 20) and d.Cout >= 1024) else (1,)
+    for c in cands:
+        for o in orders:
+            consider((c, o))
+    # tiles of 49 * 4 pixels: this network's layers have N * 49 * 4^k output pixels -- whole rounds of 256 CUs at batch 64
+    tile_px = 196 if M % 196 == 0 else 208
+    if not d.pool2:
+        for o in orders:
+            consider(("tile", 14, o, tile_px))
+    # tail plans: the two fastest large-tile configurations, cut where their tiles stop filling whole rounds of
+    # 256 (one workgroup per CU) or 512 slots, remainder with a small tile
+    if times and not d.pool2:
+        singles = sorted((pl for pl in times if isinstance(pl[0], int)), key=times.get)
+        for (c, o) in [pl for pl in singles if _TILE[pl[0]][0] * _TILE[pl[0]][1] >= 128 * 128][:2]:
+            tco, tpx = _TILE[c]
+            n_co = (d.Cout + tco - 1) // tco
+            tiles = n_co * ((M + tpx - 1) // tpx)
+            cuts = set()
+            for slots in (256, 512):
+                full = tiles // slots * slots
+                cut = full // n_co * tpx
+                if 0 < cut < M and tiles - full < 0.9 * slots:
+                    cuts.add(cut)
+            for cut in sorted(cuts):
+                for tc in _TAIL_CANDIDATES:
+                    consider((c, o, cut, tc))
+    # start-skew plans: the 8-wave configurations run one workgroup per CU, all in the same phase; over several rounds
+    # it pays to start the CUs a fraction of a tile time apart (see igemm.hip)
+    if times and not d.pool2:
+        eight = [pl for pl in sorted(times, key=times.get) if (len(pl) == 2 and pl[0] in (11, 12)) or pl[0] == "tile"][:2]
+        for pl in eight:
+            c, o, tpv = (pl[0], pl[1], 0) if isinstance(pl[0], int) else (pl[1], pl[2], pl[3])
+            tco, tpx = _TILE[c]
+            tiles = ((d.Cout + tco - 1) // tco) * ((M + (tpv or tpx) - 1) // (tpv or tpx))
+            if tiles < 400:
+                continue
+            tile_cycles = times[pl] * 1e-3 / ((tiles + 255) // 256) * 2.1e9
+            for ph, frac in ((3, 0.3), (5, 0.2), (3, 0.2), (5, 0.3)):
+                consider(("tile", c, o, tpv, ph, int(frac * tile_cycles)) if tpv else ("skew", c, o, ph, int(frac * tile_cycles)))
+    # split-K plans for few-pixel, deep-K layers (7x7x1024: 64 output tiles of 256 x 196 for 256 CUs): slabs summed in
+    # fixed order, so any split count stays bit-reproducible
+    if (times and not d.pool2 and not d.out_fp32 and M <= 8192 and d.KH * d.KW * d.tap_len >= 2304 and d.Cout % 8 == 0
+            and d.epilogue in (EPI_NONE, EPI_BIAS, EPI_BIAS_LRELU, EPI_MUL_DLRELU)):
+        for c, S, tpv in ((11, 2, 0), (5, 2, 0), (3, 2, 0), (14, 4, tile_px), (14, 2, tile_px), (12, 4, 0), (11, 4, 0)):
+            consider(("slabs", c, S, tpv))
+    d.bn_stats = stats_ptr
+    if not times:
+        return (0, 0)
+    best = min(times, key=times.get)
+    if TUNE_LOG is not None:
+        TUNE_LOG.append((_tune_key(d), best, sorted(times.items(), key=lambda kv: kv[1])[:6]))
+    return best
+
+
+TUNE_LOG: list | None = None      # tools/tune_plans.py: (key, winner, six fastest candidates with their times)
+
+
 def igemm_call(d: IgemmDesc, inp, w, bias, aux, out, st, what: str):
-    """yolo_igemm with the cached / autotuned launch plan -- only for plain, idempotent launches."""
+    """yolo_igemm with the problem's launch plan (shipped table, else the deterministic default) -- only for plain,
+    idempotent launches."""
     L_ = lib()
     plain = TILE_HINT == 0 and d.split_k <= 1 and not d.w_blocked and d.tap_len % 64 == 0
     if not plain:
-        d.tile_hint = TILE_HINT
+        d.tile_hint, d.tile_px = TILE_HINT, TILE_PX
         _igemm(L_, d, inp, w, bias, aux, out, st, what)
         return
     key = _tune_key(d)
     best = _TUNED.get(key)
-    if best is None and AUTOTUNE and TIMERS is None and d.N * d.Ho * d.Wo >= 2048:
-        dev = torch.device("cuda", torch.cuda.current_device())
-        stats_ptr, d.bn_stats = d.bn_stats, None        # tuning repeats the launch: keep it idempotent
-
-        def timed(plan):
-            try:
-                _run_plan_igemm(L_, d, plan, inp, w, bias, aux, out, st, what)
-                ts = []
-                for _ in range(3):
-                    _flush_caches(dev)
-                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                    e0.record()
-                    _run_plan_igemm(L_, d, plan, inp, w, bias, aux, out, st, what)
-                    e1.record()
-                    e1.synchronize()
-                    ts.append(e0.elapsed_time(e1))
-                return min(ts)
-            except RuntimeError:
-                return None
-
-        cands = [c for c in _TUNE_CANDIDATES if not (d.pool2 and c in (3, 12))]
-        if d.KH == 1 and d.KW == 1 and d.tap_len <= 256 and not d.pool2:
-            cands.append(10)      # thin-K 1x1 layers stream: 64x128x32, 28 KB of LDS, five workgroups per CU
-        orders = (1, 2) if (d.Cout * d.KH * d.KW * d.tap_len * 2 > (4 << 20) and d.Cout >= 1024) else (1,)
-        times = {}
-        for c in cands:
-            for o in orders:
-                t = timed((c, o))
-                if t is not None:
-                    times[(c, o)] = t
-        # tail plans: the two fastest large-tile configurations, cut where their tiles stop filling whole rounds of
-        # 256 (one workgroup per CU) or 512 slots, remainder with a small tile
-        if times and not d.pool2:
-            M = d.N * d.Ho * d.Wo
-            singles = sorted(times, key=times.get)
-            for (c, o) in [pl for pl in singles if _TILE[pl[0]][0] * _TILE[pl[0]][1] >= 128 * 128][:2]:
-                tco, tpx = _TILE[c]
-                n_co = (d.Cout + tco - 1) // tco
-                tiles = n_co * ((M + tpx - 1) // tpx)
-                cuts = set()
-                for slots in (256, 512):
-                    full = tiles // slots * slots
-                    cut = full // n_co * tpx
-                    if 0 < cut < M and tiles - full < 0.9 * slots:
-                        cuts.add(cut)
-                for cut in sorted(cuts):
-                    for tc in _TAIL_CANDIDATES:
-                        t = timed((c, o, cut, tc))
-                        if t is not None:
-                            times[(c, o, cut, tc)] = t
-        # start-skew plans: the 8-wave configurations run one workgroup per CU, all in the same phase; over several rounds
-        # it pays to start the CUs a fraction of a tile time apart (see igemm.hip)
-        if times and not d.pool2:
-            M = d.N * d.Ho * d.Wo
-            for (c, o) in [pl for pl in sorted(times, key=times.get) if len(pl) == 2 and pl[0] in (11, 12)][:2]:
-                tco, tpx = _TILE[c]
-                tiles = ((d.Cout + tco - 1) // tco) * ((M + tpx - 1) // tpx)
-                if tiles < 400:
-                    continue
-                tile_cycles = times[(c, o)] * 1e-3 / ((tiles + 255) // 256) * 2.1e9
-                for ph, frac in ((3, 0.3), (5, 0.2), (3, 0.2), (5, 0.3)):
-                    pl = ("skew", c, o, ph, int(frac * tile_cycles))
-                    t = timed(pl)
-                    if t is not None:
-                        times[pl] = t
-        # split-K plans for few-pixel, deep-K layers (7x7x1024: 200 output tiles of 128x128 for 256 CUs)
-        if (times and not d.pool2 and not d.out_fp32 and d.N * d.Ho * d.Wo <= 8192 and d.KH * d.KW * d.tap_len >= 2304 and d.Cout % 8 == 0
-                and d.epilogue in (EPI_NONE, EPI_BIAS, EPI_BIAS_LRELU, EPI_MUL_DLRELU)):
-            for c in (5, 3, 11):
-                # two K-halves only: 0 + a + b is the same fp32 number in either arrival order, so the forward stays
-                # bit-reproducible run to run (three or more partial sums would not be)
-                t = timed(("splitk", c, 2))
-                if t is not None:
-                    times[("splitk", c, 2)] = t
-        best = min(times, key=times.get) if times else (0, 0)
-        _TUNED[key] = best
-        d.bn_stats = stats_ptr
     if best is None:
-        best = (0, 0)
+        if AUTOTUNE and TIMERS is None and d.N * d.Ho * d.Wo >= 2048:
+            best = _tune(L_, d, inp, w, bias, aux, out, st, what)
+        else:
+            best = _default_plan(d)
+        _TUNED[key] = best
     _run_plan_igemm(L_, d, best, inp, w, bias, aux, out, st, what)
 
 
 def _tune_key(d: IgemmDesc):
     return (d.N, d.Ho, d.Wo, d.KH, d.KW, d.tap_len, d.Cout, d.stride, d.epilogue, d.pool2, d.out_px_stride, d.in_px_stride)
+
+
+load_plans()
 
 
 class Act:
@@ -530,8 +638,10 @@ class Plan:
         key = (N, tuple(x_shape[1:]), str(device), train)
         pool = self._ws.setdefault(key, [])
         if pool:
-            return key, pool.pop()
-        ws = {"acts": [], "grads": {}, "misc": {}}
+            ws = pool.pop()
+            self._apply_geom(ws)
+            return key, ws
+        ws = {"acts": [], "grads": {}, "misc": {}, "geom": {}}
         C, H, W = x_shape[1], x_shape[2], x_shape[3]
         if self.layers and self.layers[0].kind == "conv" and self.layers[0].first:
             a = Act(N, H, W, 4, 3, device)
@@ -553,9 +663,23 @@ class Plan:
                 flat = torch.empty((N, cur.C * cur.H * cur.W), dtype=torch.bfloat16, device=device)
                 cur = flat
             elif L.kind == "fc":
+                feat = flat.shape[1] if (flat is not None and cur is flat) else None
+                if feat is not None and feat != L.Cin:
+                    # the reference raises here too (stock nn.Linear): e.g. a 224x224 batch into the 448x448 head
+                    raise RuntimeError(f"mat1 and mat2 shapes cannot be multiplied ({N}x{feat} and {L.Cin}x{L.Cout}): input of "
+                                       f"{tuple(x_shape[2:])} pixels does not match the Linear layer behind nn.Flatten")
                 cur = None  # allocated per call (tiny)
             ws["acts"].append(cur)
+            ws["geom"][li] = (L.Hin, L.Win, L.Hout, L.Wout)
         return key, ws
+
+    def _apply_geom(self, ws):
+        """the layer geometry (Hin, Win, Hout, Wout) belongs to a workspace, not to the plan: a plan may serve several input
+        sizes, and a forward at another size may run between a training forward and its backward.  Every entry point that
+        reads ``L.Hin`` .. ``L.Wout`` calls this first with the workspace it is about to use."""
+        for li, g in ws["geom"].items():
+            L = self.layers[li]
+            L.Hin, L.Win, L.Hout, L.Wout = g
 
     def _release(self, key, ws):
         self._ws.setdefault(key, []).append(ws)
@@ -579,10 +703,11 @@ class Plan:
         d.slope = self.SLOPE
         d.out_fp32 = 0
         d.split_k = 1
-        d.tile_hint = TILE_HINT
+        d.tile_hint, d.tile_px = TILE_HINT, TILE_PX
         return d
 
     # ------------------------------------------------------------------ forward
+    @_hip.device_guard
     def forward(self, x: torch.Tensor, train: bool, drop_training: bool, u8_size=None):
         """x: NCHW fp32 device tensor -- or, with ``u8_size = (H, W)``, decoded uint8 images [N][h][w][3] that
         yolo_preprocess_u8 resizes + normalises straight into the stem's NHWC4 input buffer (no fp32 NCHW round trip).
@@ -601,6 +726,8 @@ class Plan:
                 raise ValueError("uint8 input needs a plan that starts with the 7x7/s2 stem")
             _pp.preprocess_u8_into(x, u8_size, a)
         else:
+            if x.dim() != 4 or x.shape[1] != self.in_channels:
+                raise RuntimeError(f"expected input of shape (N, {self.in_channels}, H, W), got {tuple(x.shape)}")
             if x.dtype != torch.float32 or not x.is_contiguous():
                 x = x.float().contiguous()
             key, ws = self._workspace(N, x.shape, dev, train)
@@ -751,6 +878,7 @@ class Plan:
         L_ = lib()
         st = stream()
         key, ws, fc_saved, N, dev = saved
+        self._apply_geom(ws)
         if self.arena is not None:
             self.arena[self._arena_w_end:].zero_()      # bias gradients are accumulated with atomics
         grads: dict[int, tuple] = {}
@@ -1088,6 +1216,7 @@ class PlanFunction(torch.autograd.Function):
         return out
 
     @staticmethod
+    @_hip.device_guard
     def backward(ctx, gout):
         if ctx.saved is None:
             raise RuntimeError("backward through a plan that ran without grad")
@@ -1106,6 +1235,7 @@ class ResNetTrainFunction(torch.autograd.Function):
         return out
 
     @staticmethod
+    @_hip.device_guard
     def backward(ctx, gout):
         if ctx.saved is None:
             raise RuntimeError("backward through a ResNet trunk forward that was already consumed")
@@ -1114,6 +1244,7 @@ class ResNetTrainFunction(torch.autograd.Function):
         return (None, None) + tuple(grads.get(p) if p.requires_grad else None for p in ctx.params)
 
 
+@_hip.device_guard
 def run_plan(plan: Plan, x: torch.Tensor, drop_training: bool) -> torch.Tensor:
     _hip.require_cuda(x)
     # grad mode must be sampled here: inside Function.forward it is always off
@@ -1247,6 +1378,7 @@ class ResNetPlan:
         self._bn_train(a_out, bn, relu, residual, dev, st, stats_ready=BN_STATS_IN_CONV)
         return a_out
 
+    @_hip.device_guard
     def forward_batch_stats(self, x: torch.Tensor) -> torch.Tensor:
         """the trunk with its BatchNorm layers in TRAINING mode (batch statistics, running statistics updated) -- the frozen
         backbone of the reference's default training run (trainer.py:49).  Forward only: no gradient flows into the trunk."""
@@ -1351,6 +1483,7 @@ class ResNetPlan:
         return {"tag": tag, "conv": conv, "bn": bn, "x": a_in, "z": z, "y": y, "relu": relu, "res": residual is not None, "stats": stats, "wd": wd,
                 "k": k, "s": s, "p": p}
 
+    @_hip.device_guard
     def forward_train(self, x: torch.Tensor):
         """Training-mode forward of a TRAINABLE trunk (the reference's default run, src/train.py:144: ResNetBackbone(freeze=False)):
         as forward_batch_stats, but every unit keeps its conv output z, its activation y and the batch mean / invstd.
@@ -1574,6 +1707,7 @@ class ResNetPlan:
             igemm_call(d, a_in.p, ptr(wf), ptr(b), aux, a_out.p, st, f"igemm {tag}")
         return a_out
 
+    @_hip.device_guard
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         """(N,3,H,W) fp32 on the device -> (N,2048,H/32,W/32) fp32."""
         _hip.require_cuda(x)

@@ -22,6 +22,7 @@ def _as_f32_dev(t: torch.Tensor) -> torch.Tensor:
     return t.detach().to(torch.float32).contiguous()
 
 
+@_hip.device_guard
 def decode(pred: torch.Tensor, conf_thr: float, S: int, B: int, C: int):
     """(N,S,S,5B+C) fp32 -> rec (N,S*S*B,6) f64 {cls,conf,x,y,w,h}, counts (N,) i32.
     Replaces src/yolo/inference.py:170-210 / src/yolo/metrics.py:185-218."""
@@ -33,6 +34,7 @@ def decode(pred: torch.Tensor, conf_thr: float, S: int, B: int, C: int):
     return rec, counts
 
 
+@_hip.device_guard
 def decode_gt(tgt: torch.Tensor, S: int, B: int, C: int):
     """(N,S,S,5B+C) fp32 -> rec (N,S*S,5) f64 {cls,x,y,w,h}, counts.  Replaces src/yolo/metrics.py:232-256."""
     tgt = _as_f32_dev(tgt)
@@ -43,6 +45,7 @@ def decode_gt(tgt: torch.Tensor, S: int, B: int, C: int):
     return rec, counts
 
 
+@_hip.device_guard
 def nms(rec: torch.Tensor, counts: torch.Tensor, thr: float, variant: int):
     """rec (N,M,6) f64 + counts -> keep (N,M) i32 (reference output order), keep_counts (N,).
     Replaces src/yolo/inference.py:298-317 (variant 0) / src/yolo/metrics.py:270-296 (variant 1)."""
@@ -55,6 +58,7 @@ def nms(rec: torch.Tensor, counts: torch.Tensor, thr: float, variant: int):
     return keep, kc
 
 
+@_hip.device_guard
 def pairwise_iou(a: torch.Tensor, b: torch.Tensor, variant: int) -> torch.Tensor:
     """a (na,4), b (nb,4) f64 (x,y,w,h) -> (na,nb) f64.  src/yolo/inference.py:229-249 / metrics.py:313-341."""
     _hip.require_cuda(a, b)
@@ -65,6 +69,7 @@ def pairwise_iou(a: torch.Tensor, b: torch.Tensor, variant: int) -> torch.Tensor
     return out
 
 
+@_hip.device_guard
 def map_match(rec: torch.Tensor, keep: torch.Tensor, kc: torch.Tensor, grec: torch.Tensor, gcnt: torch.Tensor, thresholds, extra_thr: float,
               small_area: float, medium_area: float):
     """TP bits of every kept prediction (see yolo_map_match) + the size bucket of every ground truth, on the device.
@@ -95,12 +100,16 @@ def postprocess_host(pred: torch.Tensor, conf_thr: float, nms_thr: float, varian
 # ------------------------------------------------------------------------------------------------
 
 
+@_hip.device_guard
 def loss_fwd_bwd(pred: torch.Tensor, tgt: torch.Tensor, S: int, B: int, C: int, lambda_coord: float, lambda_noobj: float,
                  want_grad: bool = True):
     """Fused loss forward+backward (src/yolo/loss.py:87-212).  Returns (out8 fp32 device tensor, dpred or None)."""
     pred = _as_f32_dev(pred)
     tgt = _as_f32_dev(tgt)
     N = pred.shape[0]
+    if pred.dim() != 4 or tuple(pred.shape) != (N, S, S, 5 * B + C) or tgt.shape != pred.shape:
+        # the kernel cannot know the buffers' extents: e.g. YOLOLoss(S=14) on S=7 predictions would read out of bounds
+        raise RuntimeError(f"YOLOLoss: predictions {tuple(pred.shape)} / targets {tuple(tgt.shape)} must both be (N, {S}, {S}, {5 * B + C})")
     out = torch.empty((8,), dtype=torch.float32, device=pred.device)
     dpred = torch.empty_like(pred) if want_grad else None
     work = torch.empty((N * 8,), dtype=torch.float64, device=pred.device)
@@ -109,6 +118,7 @@ def loss_fwd_bwd(pred: torch.Tensor, tgt: torch.Tensor, S: int, B: int, C: int, 
     return out, dpred
 
 
+@_hip.device_guard
 def loss_iou(b1: torch.Tensor, b2: torch.Tensor) -> torch.Tensor:
     """YOLOLoss.compute_iou (src/yolo/loss.py:174-212) with broadcasting done here."""
     b1, b2 = torch.broadcast_tensors(b1, b2)

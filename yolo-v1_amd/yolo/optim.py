@@ -26,10 +26,12 @@ def grad_norm_sq(params) -> torch.Tensor:
     """device double holding sum over all gradients of g^2 (enqueued, not synchronised): one launch
     for the whole list (yolo_sumsq_f32_multi)."""
     grads = [_f32c(p.grad) for p in params if p.grad is not None]
-    acc = torch.zeros((), dtype=torch.float64, device=grads[0].device)
-    gp = (ctypes.c_void_p * len(grads))(*[g.data_ptr() for g in grads])
-    gn = (ctypes.c_long * len(grads))(*[g.numel() for g in grads])
-    check(lib().yolo_sumsq_f32_multi(gp, gn, len(grads), ptr(acc), stream()), "yolo_sumsq_f32_multi")
+    _hip.require_cuda(*grads)
+    with torch.cuda.device(grads[0].device):
+        acc = torch.zeros((), dtype=torch.float64, device=grads[0].device)
+        gp = (ctypes.c_void_p * len(grads))(*[g.data_ptr() for g in grads])
+        gn = (ctypes.c_long * len(grads))(*[g.numel() for g in grads])
+        check(lib().yolo_sumsq_f32_multi(gp, gn, len(grads), ptr(acc), stream()), "yolo_sumsq_f32_multi")
     return acc
 
 
@@ -39,9 +41,10 @@ def clip_grad_norm_(parameters, max_norm: float) -> torch.Tensor:
     if not params:
         return torch.zeros(())
     acc = grad_norm_sq(params)
-    st = stream()
-    for p in params:
-        check(lib().yolo_clip_scale_f32(ptr(p.grad), p.grad.numel(), ptr(acc), float(max_norm), st), "yolo_clip_scale_f32")
+    with torch.cuda.device(acc.device):
+        st = stream()
+        for p in params:
+            check(lib().yolo_clip_scale_f32(ptr(p.grad), p.grad.numel(), ptr(acc), float(max_norm), st), "yolo_clip_scale_f32")
     return acc.sqrt().float()
 
 
@@ -65,6 +68,10 @@ class Adam(torch.optim.Optimizer):
         if not all_params:
             return loss
         _hip.require_cuda(*all_params)
+        with torch.cuda.device(all_params[0].device):
+            return self._step_on_device(all_params, loss)
+
+    def _step_on_device(self, all_params, loss):
         norm = grad_norm_sq(all_params) if self.max_grad_norm is not None else None
         st = stream()
         for group in self.param_groups:

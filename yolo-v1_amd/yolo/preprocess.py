@@ -22,6 +22,7 @@ import numpy as np
 import torch
 
 from ._hip import check, lib, ptr, require_cuda, stream
+from ._hip import device_guard as _hip_device_guard
 
 MEAN = (0.485, 0.456, 0.406)
 STD = (0.229, 0.224, 0.225)
@@ -65,6 +66,7 @@ def preprocess_u8_into(images: torch.Tensor, size, act, mean=MEAN, std=STD) -> N
     _run(images, size, mean, std, None, act)
 
 
+@_hip_device_guard
 def preprocess_u8(images: torch.Tensor, size=(448, 448), mean=MEAN, std=STD, nchw: bool = True, nhwc4_halo: int | None = None):
     """images: uint8 device tensor [N][H][W][3] (RGB, as decoded).  Returns (fp32 [N][3][h][w] | None, Act | None):
     the reference transform's result and / or the stem-ready NHWC4 bf16 activation (``nhwc4_halo`` = 3 for the stem)."""
