@@ -73,7 +73,8 @@ int yolo_decode_gt(const float *tgt, int N, int S, int B, int C,
  *   keep [N][max_per_img] int32: indices into the image's records in the reference's OUTPUT order;
  *   keep_counts [N].
  * A later box survives a kept one iff class differs or IoU < thr (IoU == thr suppresses).
- * Limit: max_per_img <= 128. */
+ * Limit: max_per_img <= 1024 (<= 128: suppression matrix by ballots in one pass; above, e.g. S = 14, B = 3 -> 588 boxes:
+ * row-by-row sweep with a 1024-bit mask -- same comparisons, same result). */
 int yolo_nms(const double *rec, const int32_t *counts, int N, int max_per_img, double thr, int variant,
              int32_t *keep, int32_t *keep_counts, yolo_stream_t stream);
 
@@ -145,7 +146,9 @@ typedef struct yolo_igemm_desc {
                                (8 waves, 3 stages), 3: 128x64, 4: 64x128, 5/6: 1/2 on the 16x16x32
                                MFMA shape, 11: 256x128x64 and 12: 256x256x32 / 13: 256x128x32 with the staggered
                                two-phase schedule (8 waves), 14: 256 x 208 x 32 staggered with an uneven 7 / 6 column
-                               split between the wave groups (see tile_px), 7-10: BK = 32 variants of 64x128  (tuning / tests;
+                               split between the wave groups (see tile_px), 15: the same tile with the register-pipelined
+                               one-barrier loop (even number >= 4 of 32-deep K steps per split; no pool2 / bn_stats /
+                               atomics), 7-10: BK = 32 variants of 64x128  (tuning / tests;
                                a caller that wants the best plan times them per problem, as engine.igemm_call does) */
     int64_t px_begin, px_end; /* compute only output pixels [px_begin, px_end) of the flattened (n, oy, ox) index
                                (0, 0 = all).  Lets a caller run the bulk of a layer with a large tile in whole

@@ -363,7 +363,7 @@ def test_fc_dgrad_behind_flatten_matches_cpu():
         _close(a, b, 3.0, n, frac=0.01)
 
 
-@pytest.mark.parametrize("hint", [1, 2, 3, 4, 5, 6, 10, 11, 12, 13, 14, (14, 196), (14, 49), (12, 196), (5, 98)])
+@pytest.mark.parametrize("hint", [1, 2, 3, 4, 5, 6, 10, 11, 12, 13, 14, (14, 196), (14, 49), (12, 196), (5, 98), 15, (15, 196), (15, 49)])
 def test_every_tile_configuration(hint):
     """the same 3x3 / 1x1 chain through each yolo_igemm tile configuration (128x128, 256x128 8-wave
     3-stage ring, 128x64, 64x128, 256x208 with the uneven staggered split), forward and data-gradient, with ragged pixel
@@ -431,11 +431,12 @@ def test_pixel_range_launches_tile_the_output_exactly():
     # tiles limited to tile_px pixels (hint 14: uneven staggered split) against the plain 128x128 launch
     ref = run((5, 1))
     for pl in (("tile", 14, 1, 0), ("tile", 14, 1, 196), ("tile", 14, 1, 100), ("tile", 12, 1, 196), ("tile", 14, 1, 196, 3, 4000),
-               ("slabs", 14, 3, 196)):
+               ("slabs", 14, 3, 196), ("tile", 15, 1, 0), ("tile", 15, 1, 196), ("tile", 15, 2, 100), ("tile", 15, 1, 196, 3, 4000), ("slabs", 15, 3, 196)):
         got = run(pl)
         _close(got.permute(0, 3, 1, 2), ref.permute(0, 3, 1, 2).float(), 2.0, f"plan {pl}")
         assert torch.equal(run(pl), got), pl
     assert torch.equal(run(("tile", 14, 1, 196)), run(("tile", 14, 1, 0)))    # same K order per output: bit-identical
+    assert torch.equal(run(("tile", 15, 1, 196)), run(("tile", 14, 1, 196)))  # the pipelined loop adds in the same order too
     d.px_begin, d.px_end = 10, 5
     assert lib().yolo_igemm(ctypes.byref(d), a_in.p, ptr(wf), ptr(L.bias.detach()), None, a_out.p, stream()) != 0
     plan._release(key, ws)

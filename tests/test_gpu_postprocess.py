@@ -160,3 +160,82 @@ def test_device_side_map_matching_equals_host_protocol():
     m2.all_predictions.append([(0, 0.9, (0.5, 0.5, 0.2, 0.2))])
     m2.all_ground_truths.append([(0, (0.5, 0.5, 0.2, 0.2))])
     assert abs(m2.compute()["mAP50"] - 1.0 / 20) < 1e-6
+
+
+def test_nms_beyond_128_boxes_bit_exact(ops):
+    """grids with S*S*B > 128 (the reference's tests build S = 14, B = 3: tests/test_backbone.py:141-173 -> 588 boxes per
+    image): yolo_nms sweeps row by row with a 1024-bit mask -- records, kept indices and both output orders equal the
+    oracle's; confidence ties and equal boxes included; more than 1024 boxes are refused loudly."""
+    S, B, C = 14, 3, 20
+    rng = np.random.Generator(np.random.PCG64([14, 3]))
+    pred = rng.uniform(0, 1, size=(5, S, S, 5 * B + C)).astype(np.float32)
+    pred[1, :, :, 4::5][:, :, :B] = np.float32(0.5)          # whole image at one confidence: ties keep the scan order
+    pred[2, ...] = pred[2, 0:1, 0:1, :]                      # every cell predicts the same box offsets and class
+    for ct, nt in ((0.05, 0.4), (0.3, 0.5)):
+        rec, cnt = ops.decode(torch.from_numpy(pred).cuda(), ct, S, B, C)
+        assert rec.shape[1] == S * S * B == 588
+        rec_h, cnt_h = rec.cpu().numpy(), cnt.cpu().numpy()
+        assert cnt_h.max() > 128
+        for variant in (0, 1):
+            keep, kc = ops.nms(rec, cnt, nt, variant)
+            keep_h, kc_h = keep.cpu().numpy(), kc.cpu().numpy()
+            for n in range(pred.shape[0]):
+                ref_rec = O.decode(pred[n], ct, S, B, C)
+                assert np.array_equal(rec_h[n, : cnt_h[n]], ref_rec), (n, ct)
+                assert np.array_equal(keep_h[n, : kc_h[n]], O.nms(ref_rec, nt, variant)), (n, ct, variant)
+    too_many = torch.zeros((1, 1025, 6), dtype=torch.float64, device="cuda")
+    with pytest.raises(RuntimeError):
+        ops.nms(too_many, torch.tensor([1025], dtype=torch.int32, device="cuda"), 0.4, 0)
+
+
+def test_inference_nms_of_a_gpu_model_stays_on_the_device():
+    """YOLOInference.non_max_suppression with a model on the GPU and more than 128 detections (S = 14, B = 3) runs yolo_nms,
+    not a host loop, and returns the reference order (src/yolo/inference.py:283-317)."""
+    import torch.nn as nn
+    from yolo.inference import YOLOInference
+    from yolo.schemas import BoundingBox, Detection
+
+    class Tiny(nn.Module):
+        S, B = 14, 3
+
+        def __init__(self):
+            super().__init__()
+            self.p = nn.Parameter(torch.zeros(1))
+
+    inf = YOLOInference(Tiny().cuda(), device="cuda")
+    rng = np.random.Generator(np.random.PCG64([5, 88]))
+    dets = [Detection(bbox=BoundingBox(x=float(rng.uniform(0.2, 0.8)), y=float(rng.uniform(0.2, 0.8)), width=float(rng.uniform(0.1, 0.4)),
+                                       height=float(rng.uniform(0.1, 0.4))), confidence=float(rng.uniform(0.05, 1.0)), class_id=int(rng.integers(0, 4)))
+            for _ in range(300)]
+    rec = np.array([[d.class_id, d.confidence, d.bbox.x, d.bbox.y, d.bbox.width, d.bbox.height] for d in dets], np.float64)
+    import yolo._post_cpu as pc
+    called = []
+    orig = pc.nms
+    pc.nms = lambda *a, **k: called.append(1) or orig(*a, **k)
+    try:
+        kept = inf.non_max_suppression(dets, nms_threshold=0.4)
+    finally:
+        pc.nms = orig
+    assert not called, "a GPU model must not fall back to the host NMS loop"
+    assert [dets.index(k) for k in kept] == O.nms(rec, 0.4, 0).tolist()
+
+
+def test_map_case_fixture_through_the_device_path():
+    """SURVEY 8f-3 / a11 pinned to the reference: the reference-run fixture tests/golden/map_case.{npz,json} (make_golden.py
+    ran the reference's mAPMetric on these tensors) fed through mAPMetric.update on DEVICE tensors -- yolo_decode, yolo_nms,
+    yolo_decode_gt and yolo_map_match -- must reproduce every key of the reference's compute() dictionary."""
+    import json, os
+    from yolo.metrics import mAPMetric
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    d = np.load(os.path.join(here, "map_case.npz"))
+    ref = json.load(open(os.path.join(here, "map_case.json")))
+    m = mAPMetric(20, conf_threshold=0.05, nms_threshold=0.4)
+    pred, tgt = torch.from_numpy(d["pred"]).cuda(), torch.from_numpy(d["tgt"]).cuda()
+    half = pred.shape[0] // 2
+    m.update(pred[:half], tgt[:half])          # two device batches
+    m.update(pred[half:], tgt[half:])
+    assert m._dev_images == pred.shape[0] == len(m.all_predictions), "the device matching path must have been taken"
+    res = m.compute()
+    assert set(res) == set(ref)
+    for k, v in ref.items():
+        assert float(res[k]) == pytest.approx(v, abs=1e-12), k

@@ -309,3 +309,26 @@ def test_north_star_functional_spellings():
     tgt = torch.zeros(2, 7, 7, 30)
     out = yolo.mean_average_precision(pred, tgt)
     assert "mAP50:95" in out and yolo.YoloLoss is yolo.YOLOLoss
+
+
+def test_draw_detections_takes_the_reference_call():
+    """src/predict.py:113 calls draw_detections(image, detections, class_names, conf_threshold) against
+    src/yolo/utils/visualization.py:34-41: same positional meaning, a copy is returned, low-confidence boxes are skipped,
+    legacy (class_id, conf, x, y, w, h) tuples are accepted."""
+    import inspect
+    from PIL import Image
+    from yolo.schemas import BoundingBox, Detection
+    from yolo.utils import VOC_CLASSES, draw_detections
+    assert list(inspect.signature(draw_detections).parameters) == ["image", "detections", "class_names", "conf_threshold", "box_width", "font_size"]
+    img = Image.new("RGB", (200, 100), "black")
+    dets = [Detection(bbox=BoundingBox(x=0.5, y=0.5, width=0.4, height=0.4), confidence=0.9, class_id=11, class_name="dog"),
+            Detection(bbox=BoundingBox(x=0.2, y=0.2, width=0.2, height=0.2), confidence=0.2, class_id=3, class_name="boat")]
+    out = draw_detections(img, dets, VOC_CLASSES, 0.5)
+    assert out is not img and out.size == img.size and img.getbbox() is None        # the input is untouched
+    px = out.load()
+    assert px[60, 50] != (0, 0, 0) and px[139, 50] != (0, 0, 0)                     # left / right edge of the 0.9 box
+    assert px[30, 20] == (0, 0, 0)                                                  # the 0.2 box is below the threshold
+    assert draw_detections(img, dets, VOC_CLASSES, 0.1).load()[20, 20] != (0, 0, 0)
+    legacy = draw_detections(img, [(11, 0.9, 0.5, 0.5, 0.4, 0.4)], VOC_CLASSES)
+    assert legacy.load()[60, 50] == px[60, 50]
+    assert draw_detections(img, dets, box_width=1, font_size=10).size == img.size   # keyword form of the remaining parameters

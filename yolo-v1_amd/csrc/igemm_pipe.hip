@@ -1,0 +1,379 @@
+// Register-pipelined implicit-GEMM kernel for gfx950 (tile_hint 15): 256 output channels x 208 pixel slots, BK = 32,
+// four LDS stages, eight waves, ONE workgroup barrier per K step and no phases.
+//
+// Why (measured with in-kernel s_memtime stamps on the staggered kernels, tools/stamps_igemm.py): per K step a wave spends
+// ~200 cycles issuing its 11 ds_read_b128 (the LDS array serves the four waves of a group at once), 250-390 cycles issuing
+// its four global_load_lds and ~450-520 cycles issuing 24-28 MFMAs.  With the K step cut into an L phase and an M phase
+// the L phase (reads + DMA, ~560 cycles) is LONGER than the partner wave's M phase (~450), so the matrix pipe idles 40 %
+// of the time however the phases are paired.  Here every wave has two register sets of fragments and, in step k,
+//     * runs the MFMAs of step k on set k & 1,
+//     * reads the fragments of step k+1 into the other set   -- one ds_read behind each of the first MFMAs,
+//     * issues its share of the LDS-DMA of stage k+3          -- one global_load_lds every few MFMAs,
+// so the LDS / texture-path work of a wave hides under its own and its SIMD partner's MFMAs.  The interleave is pinned
+// with sched_group_barrier; the step is one basic block (no branches: the tail steps are separate code).
+//
+//   top of step k:  s_waitcnt vmcnt(4)  -- this wave's pieces of stage k+1 have landed (stage k+2 may be in flight)
+//                   s_barrier           -- everyone's pieces are visible; everyone has issued the MFMAs of step k-1, i.e. has
+//                                          finished READING buffer (k-1) % 4, which the DMA of stage k+3 overwrites
+//
+// Tile geometry, LDS image (XOR-swizzled 64-B rows, swizzle on the DMA's source lane), the uneven 7 / 6 column split of
+// the two wave groups (one wave of each group per SIMD), tile_px, slabs and the epilogue are those of tile_hint 14
+// (igemm.hip).  LDS-DMA sources are addressed as scalar base + per-lane 32-bit offset (saddr form): the per-step address
+// arithmetic is scalar.  Not available here: pooled epilogue, BatchNorm statistics, fp32 atomics (split_k needs slabs),
+// blocked Linear weights -- yolo_igemm routes those to the other configurations.
+#include "igemm_common.h"
+
+namespace yolo {
+
+namespace pipe {
+constexpr int TCO = 256, TPX = 208, BK = 32, NST = 4, NW = 8, WCO = 4, NTHR = NW * 64;
+constexpr int A_BYTES = TCO * BK * 2;             // 16 KB
+constexpr int B_BYTES = 256 * BK * 2;             // 16 KB: 208 rows used, the pad rows are loaded from one line and never read
+constexpr int STAGE_BYTES = A_BYTES + B_BYTES;
+constexpr int MT = 4, NT0 = 7, NT1 = 6;           // 16x16 MFMA tiles per wave: 64 channels x 112 (group A) / 96 (group B) pixels
+constexpr int EP = TCO + 4;                       // fp32 epilogue row pitch (floats)
+constexpr int PPX = NT0 * 16;                     // pixels per epilogue pass
+constexpr int TABLE_BYTES = TPX * 32;
+constexpr int LDS_BYTES = TABLE_BYTES + NST * STAGE_BYTES;
+constexpr int LOADS = 4;                          // LDS-DMA instructions per wave and stage (2 weight pieces + 2 pixel pieces)
+static_assert(PPX * EP * 4 <= NST * STAGE_BYTES, "epilogue slab must fit into the stage area");
+}  // namespace pipe
+
+#define GLDS16_S(base, voff, lptr) \
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)((const char *)(base) + (unsigned long)(voff)), \
+                                     (__attribute__((address_space(3))) void *)(lptr), 16, 0, 0)
+
+__global__ void __launch_bounds__(pipe::NTHR, 2) igemm_pipe_kernel(const IgemmParams p)
+{
+    using namespace pipe;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    long *tab = reinterpret_cast<long *>(smem);
+    char *stage_base = smem + TABLE_BYTES;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wco = wave % WCO, grp = wave / WCO;          // grp 0: pixel columns 0..6, grp 1: 7..12
+    const int px_lo = grp * NT0 * 16;
+
+    // start skew (see igemm.hip)
+    if (p.skew_phases > 1 && gridDim.x * gridDim.y > 256 && blockIdx.y == 0 && blockIdx.x < 256) {
+        const int ph = (blockIdx.x >> 3) % p.skew_phases;
+        if (ph) {
+            const long t0 = __builtin_amdgcn_s_memtime(), wait = ph * p.skew_cycles;
+            while ((long)__builtin_amdgcn_s_memtime() - t0 < wait) __builtin_amdgcn_s_sleep(16);
+        }
+    }
+
+    // XCD-aware tile mapping (bijective; see igemm.hip)
+    const int nwg = p.n_co_tiles * p.n_px_tiles;
+    int bid = blockIdx.x;
+    {
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, k = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+    }
+    const int co_tile = p.px_fastest ? bid / p.n_px_tiles : bid % p.n_co_tiles;
+    const int px_tile = p.px_fastest ? bid % p.n_px_tiles : bid / p.n_co_tiles;
+    const int co0 = co_tile * TCO;
+    const int tpv = p.tpx_valid;
+    const long px0 = p.px_begin + (long)px_tile * tpv;
+
+    // per-pixel address table: input row base / output base / aux base (elements), one pixel per thread
+    if (tid < TPX) {
+        long m = px0 + tid;
+        const bool valid = m < p.M && tid < tpv;
+        if (!valid) m = p.M - 1;
+        const int n = (int)(m / p.HoWo);
+        const int rem = (int)(m - (long)n * p.HoWo);
+        const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+        tab[4 * tid] = (long)n * p.in_img_stride + (long)(oy * p.stride) * p.in_row_stride + (long)(ox * p.stride) * p.in_px_stride + p.in_off;
+        tab[4 * tid + 1] = valid ? ((long)n * p.out_img_stride + (long)oy * p.out_row_stride + (long)ox * p.out_px_stride + p.out_off) : -1;
+        tab[4 * tid + 2] = (long)n * p.aux_img_stride + (long)oy * p.aux_row_stride + (long)ox * p.aux_px_stride + p.aux_off;
+    }
+    __syncthreads();
+
+    // LDS-DMA pieces of this wave: weight pieces q = wave, wave + 8; pixel pieces likewise.  Lane -> (row, 16-B chunk) through the
+    // inverse swizzle (the DMA writes lane-linear), as a 32-bit BYTE offset from the operand's base pointer.
+    unsigned a_voff[2], b_voff[2];
+    int a_dst[2], b_dst[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int q = i * NW + wave;
+        const int pos = q * 64 + lane;
+        const int R = pos >> 4, s = (pos & 15) ^ swz_key<BK, true>(R);
+        const int r = R * 4 + s / 4, chunk = s % 4;
+        int co = co0 + r;
+        if (co >= p.Cout) co = p.Cout - 1;
+        a_voff[i] = (unsigned)(((long)co * p.Ktot + chunk * 8) * 2);
+        a_dst[i] = q * 1024;
+        b_voff[i] = (unsigned)((r < TPX ? tab[4 * r] + chunk * 8 : tab[0]) * 2);
+        b_dst[i] = A_BYTES + q * 1024;
+    }
+
+    // K range of this split
+    const int kbeg = blockIdx.y * p.nk_per_split;
+    const int kend = min(p.nk, kbeg + p.nk_per_split);
+    const int nkk = kend - kbeg;
+    const int cpt = p.tap_len / BK;
+    // scalar staging state: byte offset of the next stage's weight columns, and (ky, kx, c0) of its tap
+    unsigned a_soff = (unsigned)kbeg * (BK * 2);
+    int tap = kbeg / cpt;
+    int c0 = (kbeg - tap * cpt) * BK;
+    int ky = tap / p.KW, kx = tap - ky * p.KW;
+
+    auto stage = [&](int buf) {
+        char *sb = stage_base + buf * STAGE_BYTES;
+        const unsigned b_soff = (unsigned)((ky * p.in_row_stride + kx * p.in_px_stride + c0) * 2);
+        const char *wb = reinterpret_cast<const char *>(p.w) + a_soff;
+        const char *xb = reinterpret_cast<const char *>(p.in) + b_soff;
+        GLDS16_S(wb, a_voff[0], sb + a_dst[0]);
+        GLDS16_S(wb, a_voff[1], sb + a_dst[1]);
+        GLDS16_S(xb, b_voff[0], sb + b_dst[0]);
+        GLDS16_S(xb, b_voff[1], sb + b_dst[1]);
+        // advance to the next K step without branches (the step must stay one basic block)
+        a_soff += BK * 2;
+        c0 += BK;
+        const int w0 = c0 == p.tap_len;
+        c0 = w0 ? 0 : c0;
+        kx += w0;
+        const int w1 = kx == p.KW;
+        kx = w1 ? 0 : kx;
+        ky += w1;
+    };
+
+    // fragment read offsets (bytes inside a stage): lane l reads row (l & 15), chunk (l >> 4) of each 16-row MFMA operand
+    int a_rd[MT], b_rd[NT0];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) a_rd[i] = lds_off<BK, true>(wco * 64 + i * 16 + (lane & 15), lane >> 4);
+#pragma unroll
+    for (int j = 0; j < NT0; ++j) {
+        int row = px_lo + j * 16 + (lane & 15);
+        if (row >= TPX) row = TPX - 1;                  // group B's seventh column does not exist (never read)
+        b_rd[j] = A_BYTES + lds_off<BK, true>(row, lane >> 4);
+    }
+
+    f32x4 acc[MT][NT0];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT0; ++j) acc[i][j] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+
+    // ---- prologue: stages 0 .. 2 in flight, stage 0 landed and visible
+    constexpr int D = NST - 1;
+#pragma unroll
+    for (int s0 = 0; s0 < D; ++s0)
+        if (s0 < nkk) stage(s0);
+    if (nkk >= D) wait_vmcnt<(D - 1) * LOADS>();
+    else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+
+    auto run = [&](auto ntc) {
+        constexpr int NTG = decltype(ntc)::value;
+        bf16x8 a0[MT], b0[NT0], a1[MT], b1[NT0];
+        auto rd = [&](int buf, bf16x8(&af)[MT], bf16x8(&bfr)[NT0]) {
+            const char *sb = stage_base + buf * STAGE_BYTES;
+#pragma unroll
+            for (int i = 0; i < MT; ++i) af[i] = *reinterpret_cast<const bf16x8 *>(sb + a_rd[i]);
+#pragma unroll
+            for (int j = 0; j < NTG; ++j) bfr[j] = *reinterpret_cast<const bf16x8 *>(sb + b_rd[j]);
+        };
+        auto mm = [&](bf16x8(&af)[MT], bf16x8(&bfr)[NT0]) {
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NTG; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+        };
+        // steady-state step: reads of stage it+1, DMA of stage it+D, MFMAs of step it -- one basic block
+        auto step = [&](int rbuf, int lbuf, bf16x8(&ca)[MT], bf16x8(&cb)[NT0], bf16x8(&na)[MT], bf16x8(&nb)[NT0]) {
+            wait_vmcnt<(D - 2) * LOADS>();
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            rd(rbuf, na, nb);
+            stage(lbuf);
+            mm(ca, cb);
+            constexpr int NRD = MT + NTG, NMF = MT * NTG;
+            // one ds_read behind each of the first NRD MFMAs ...
+#pragma unroll
+            for (int k = 0; k < NRD; ++k) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+            // ... then one LDS-DMA every PER MFMAs
+            constexpr int PER = (NMF - NRD) / (LOADS + 1);
+#pragma unroll
+            for (int k = 0; k < LOADS; ++k) {
+                __builtin_amdgcn_sched_group_barrier(0x008, PER, 0);
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, NMF - NRD - LOADS * PER, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        // the last steps stage nothing.  TOP = 1: stage k+1 and one younger stage are in flight (counted wait), TOP = 0: only
+        // stage k+1 is (wait for everything), TOP < 0: final step, nothing to read, no barrier
+        auto tail = [&](auto topc, int rbuf, bf16x8(&ca)[MT], bf16x8(&cb)[NT0], bf16x8(&na)[MT], bf16x8(&nb)[NT0]) {
+            constexpr int TOP = decltype(topc)::value;
+            if constexpr (TOP >= 0) {
+                wait_vmcnt<TOP * LOADS>();
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+                rd(rbuf, na, nb);
+            }
+            mm(ca, cb);
+            if constexpr (TOP >= 0) {
+                constexpr int NRD = MT + NTG;
+#pragma unroll
+                for (int k = 0; k < NRD; ++k) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
+                __builtin_amdgcn_sched_group_barrier(0x008, MT * NTG - NRD, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        // nkk is even and >= 4 (checked by the host): all steps but the last three stage something, in pairs; the register sets
+        // and the tail are static -- no run-time parity, no merging of the two fragment sets
+        rd(0, a0, b0);
+        int rbuf = 1, lbuf = D;
+        auto adv = [&]() {
+            rbuf = (rbuf + 1) & (NST - 1);
+            lbuf = (lbuf + 1) & (NST - 1);
+        };
+        for (int it = 0; it + 4 < nkk; it += 2) {
+            step(rbuf, lbuf, a0, b0, a1, b1);
+            adv();
+            step(rbuf, lbuf, a1, b1, a0, b0);
+            adv();
+        }
+        step(rbuf, lbuf, a0, b0, a1, b1);                                       // step nkk-4: stages the last stage
+        adv();
+        tail(std::integral_constant<int, 1>{}, rbuf, a1, b1, a0, b0);           // step nkk-3
+        adv();
+        tail(std::integral_constant<int, 0>{}, rbuf, a0, b0, a1, b1);           // step nkk-2
+        adv();
+        tail(std::integral_constant<int, -1>{}, rbuf, a1, b1, a0, b0);          // step nkk-1
+    };
+    if (grp == 0) run(std::integral_constant<int, NT0>{});
+    else run(std::integral_constant<int, NT1>{});
+
+    wait_vmcnt<0>();
+    __syncthreads();  // all MFMA operand reads done before the stage area is reused for the epilogue
+
+    // ---- epilogue (as igemm.hip, uneven split): two passes -- group A's 112 pixels, group B's 96 -- through an fp32 slab
+    // [px][co] in LDS, then 16-B coalesced stores along the channel axis with the layer's epilogue applied
+    float *ep = reinterpret_cast<float *>(stage_base);
+    constexpr int CCH = TCO / 8;
+    constexpr int PX_PER_STEP = NTHR / CCH;
+    const int cc = tid % CCH;
+    const int co = co0 + cc * 8;
+    const bool has_bias = p.epilogue == YOLO_EPI_BIAS || p.epilogue == YOLO_EPI_BIAS_LRELU || p.epilogue == YOLO_EPI_BIAS_ADD_LRELU;
+    float bias8[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) bias8[k] = has_bias && (co + k < p.Cout) ? p.bias[co + k] : 0.0f;
+    void *const outp = p.slab_stride ? (void *)(reinterpret_cast<float *>(p.out) + (long)blockIdx.y * p.slab_stride) : p.out;
+
+    for (int q = 0; q < 2; ++q) {
+        if (q > 0) __syncthreads();
+        if (grp == q) {
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT0; ++j) {
+                    const int lp = j * 16 + (lane & 15);
+                    const int cob = wco * 64 + i * 16 + 4 * (lane >> 4);
+                    *reinterpret_cast<f32x4 *>(ep + lp * EP + cob) = acc[i][j];
+                }
+        }
+        __syncthreads();
+        const int pbase = q * PPX;
+        const int ppx_q = q == 1 ? NT1 * 16 : PPX;
+#pragma unroll 2
+        for (int lp = tid / CCH; lp < ppx_q; lp += PX_PER_STEP) {
+            const int px = pbase + lp;
+            const long ob = tab[4 * px + 1];
+            if (ob < 0 || co >= p.Cout) continue;
+            float v[8];
+            const f32x4 lo = *reinterpret_cast<const f32x4 *>(ep + lp * EP + cc * 8);
+            const f32x4 hi = *reinterpret_cast<const f32x4 *>(ep + lp * EP + cc * 8 + 4);
+            v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3];
+            v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
+            if (has_bias) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v[k] += bias8[k];
+            }
+            if (p.epilogue == YOLO_EPI_BIAS_ADD_LRELU) {
+                const uint4 y = *reinterpret_cast<const uint4 *>(p.aux + tab[4 * px + 2] + co);
+                const unsigned yy[4] = {y.x, y.y, y.z, y.w};
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    v[k] += __uint_as_float((k & 1) ? (yy[k >> 1] & 0xffff0000u) : (yy[k >> 1] << 16));
+                    v[k] = v[k] > 0.0f ? v[k] : v[k] * p.slope;
+                }
+            } else if (p.epilogue == YOLO_EPI_BIAS_LRELU) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v[k] = v[k] > 0.0f ? v[k] : v[k] * p.slope;
+            } else if (p.epilogue == YOLO_EPI_MUL_DLRELU) {
+                const uint4 y = *reinterpret_cast<const uint4 *>(p.aux + tab[4 * px + 2] + co);
+                const unsigned yy[4] = {y.x, y.y, y.z, y.w};
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const float a = __uint_as_float((k & 1) ? (yy[k >> 1] & 0xffff0000u) : (yy[k >> 1] << 16));
+                    v[k] = a > 0.0f ? v[k] : v[k] * p.slope;
+                }
+            }
+            if (p.out_fp32) {
+                float *o = reinterpret_cast<float *>(outp) + ob + co;
+                if (co + 8 <= p.Cout && ((ob + co) & 3) == 0) {
+                    *reinterpret_cast<f32x4 *>(o) = f32x4{v[0], v[1], v[2], v[3]};
+                    *reinterpret_cast<f32x4 *>(o + 4) = f32x4{v[4], v[5], v[6], v[7]};
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k)
+                        if (co + k < p.Cout) o[k] = v[k];
+                }
+            } else {
+                bf16_t *o = reinterpret_cast<bf16_t *>(p.out) + ob + co;
+                uint4 pk;
+                pk.x = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
+                pk.y = (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
+                pk.z = (unsigned)f32_to_bf16(v[4]) | ((unsigned)f32_to_bf16(v[5]) << 16);
+                pk.w = (unsigned)f32_to_bf16(v[6]) | ((unsigned)f32_to_bf16(v[7]) << 16);
+                *reinterpret_cast<uint4 *>(o) = pk;
+            }
+        }
+    }
+}
+
+int igemm_pipe_launch(const IgemmParams &p, int splits, hipStream_t s)
+{
+    using namespace pipe;
+    if (p.pool || p.stats || p.w_blocked) return fail(YOLO_E_UNSUPPORTED, "yolo_igemm: tile_hint 15 has no pooled epilogue, BatchNorm statistics or blocked weights");
+    if (splits > 1 && !p.slab_stride) return fail(YOLO_E_UNSUPPORTED, "yolo_igemm: tile_hint 15 splits K into slabs only (split_slabs = 1)");
+    if (p.tap_len % BK) return fail(YOLO_E_UNSUPPORTED, "yolo_igemm: tile_hint 15 needs tap_len %% 32 == 0");
+    // the loop runs its K steps in pairs with a static four-step tail: every split needs an even number (>= 4) of K steps
+    const long nk_all = p.Ktot / BK;
+    if (nk_all % (2 * splits) || nk_all / splits < 4) return fail(YOLO_E_UNSUPPORTED, "yolo_igemm: tile_hint 15 needs an even number (>= 4) of 32-deep K steps per split");
+    // the DMA sources are addressed as base + 32-bit byte offset
+    const long in_bytes = ((p.M / p.HoWo) * p.in_img_stride + (long)p.KH * p.in_row_stride) * 2, w_bytes = (long)p.Cout * p.Ktot * 2;
+    if (in_bytes >= (1L << 32) || w_bytes >= (1L << 32)) return fail(YOLO_E_UNSUPPORTED, "yolo_igemm: tile_hint 15 addresses operands below 4 GB");
+    static bool attr_done[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    if (!attr_done[dev]) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&igemm_pipe_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        if (e != hipSuccess) return fail((int)e, "yolo_igemm: hipFuncSetAttribute(%d B LDS): %s", LDS_BYTES, hipGetErrorString(e));
+        attr_done[dev] = true;
+    }
+    IgemmParams q = p;
+    q.n_co_tiles = (p.Cout + TCO - 1) / TCO;
+    if (q.tpx_valid <= 0 || q.tpx_valid > TPX) q.tpx_valid = TPX;
+    q.n_px_tiles = (int)((p.M - p.px_begin + q.tpx_valid - 1) / q.tpx_valid);
+    q.nk = (int)(p.Ktot / BK);
+    if (p.px_fastest < 0) q.px_fastest = 0;
+    q.nk_per_split = (q.nk + splits - 1) / splits;
+    const int real_splits = p.slab_stride ? splits : 1;
+    hipLaunchKernelGGL(igemm_pipe_kernel, dim3(q.n_co_tiles * q.n_px_tiles, real_splits), dim3(NTHR), LDS_BYTES, s, q);
+    return check_launch("yolo_igemm (pipelined)");
+}
+
+}  // namespace yolo

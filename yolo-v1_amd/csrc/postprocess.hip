@@ -257,6 +257,90 @@ __global__ void __launch_bounds__(256) nms_kernel(const double *__restrict__ rec
 }
 
 // ------------------------------------------------------------------------------------------------
+// NMS for 128 < n <= 1024 boxes per image (grids beyond S*S*B = 128, e.g. the reference's S = 14, B = 3 test model:
+// 588 boxes).  Same order of comparisons and the same results as nms_kernel; the suppression matrix would not fit into LDS
+// (1024 x 16 words), so the greedy sweep is done row by row: for every box that is still alive (rank order) the 256 threads
+// test the later same-class boxes in parallel and OR their "removed" bits into a 1024-bit mask in LDS.
+// ------------------------------------------------------------------------------------------------
+constexpr int NMS_BIG_MAX = 1024;
+
+template <int VARIANT>
+__global__ void __launch_bounds__(256) nms_big_kernel(const double *__restrict__ rec, const int *__restrict__ counts, int max_per_img,
+                                                      double thr, int *__restrict__ keep, int *__restrict__ keep_counts)
+{
+    const int img = blockIdx.x;
+    const int tid = threadIdx.x;
+    int n = counts[img];
+    if (n > max_per_img) n = max_per_img;
+    const double *r = rec + (size_t)img * max_per_img * 6;
+    int *kout = keep + (size_t)img * max_per_img;
+
+    __shared__ double s_conf[NMS_BIG_MAX];         // scan order
+    __shared__ double s_box[NMS_BIG_MAX][4];       // rank order
+    __shared__ float s_cls[NMS_BIG_MAX];           // rank order (class ids are small integers: exact in fp32)
+    __shared__ short s_orig[NMS_BIG_MAX], s_first[NMS_BIG_MAX], s_kept[NMS_BIG_MAX];
+    __shared__ unsigned int s_removed[NMS_BIG_MAX / 32];
+    __shared__ int s_nk;
+
+    for (int i = tid; i < n; i += 256) s_conf[i] = r[(size_t)i * 6 + 1];
+    if (tid < NMS_BIG_MAX / 32) s_removed[tid] = 0u;
+    __syncthreads();
+    for (int i = tid; i < n; i += 256) {
+        const double c = s_conf[i];
+        int rank = 0;
+        for (int j = 0; j < n; ++j) {
+            const double cj = s_conf[j];
+            rank += (cj > c) || (cj == c && j < i);
+        }
+        s_orig[rank] = (short)i;
+        s_cls[rank] = (float)r[(size_t)i * 6 + 0];
+        s_box[rank][0] = r[(size_t)i * 6 + 2];
+        s_box[rank][1] = r[(size_t)i * 6 + 3];
+        s_box[rank][2] = r[(size_t)i * 6 + 4];
+        s_box[rank][3] = r[(size_t)i * 6 + 5];
+    }
+    __syncthreads();
+    if (VARIANT == YOLO_NMS_METRICS) {
+        for (int i = tid; i < n; i += 256) {
+            const float ct = s_cls[i];
+            int first = i;
+            for (int j = 0; j < i; ++j)
+                if (s_cls[j] == ct) { first = j; break; }
+            s_first[i] = (short)first;
+        }
+    }
+    int nk = 0;                                    // the same value in every thread
+    for (int a = 0; a < n; ++a) {
+        if ((s_removed[a >> 5] >> (a & 31)) & 1u) continue;          // uniform: read after the barrier of the previous row
+        if (tid == 0) s_kept[nk] = (short)a;
+        ++nk;
+        const float ca = s_cls[a];
+        const double xa = s_box[a][0], ya = s_box[a][1], wa = s_box[a][2], ha = s_box[a][3];
+        for (int b = a + 1 + tid; b < n; b += 256) {
+            if (s_cls[b] != ca) continue;
+            if (!(iou_f64<VARIANT>(xa, ya, wa, ha, s_box[b][0], s_box[b][1], s_box[b][2], s_box[b][3]) < thr)) atomicOr(&s_removed[b >> 5], 1u << (b & 31));
+        }
+        __syncthreads();
+    }
+    if (tid == 0) s_nk = nk;
+    __syncthreads();
+    if (VARIANT == YOLO_NMS_INFERENCE) {
+        for (int i = tid; i < nk; i += 256) kout[i] = s_orig[s_kept[i]];
+    } else {
+        for (int i = tid; i < nk; i += 256) {
+            const int a = s_kept[i], first = s_first[a];
+            int pos = 0;
+            for (int q = 0; q < nk; ++q) {
+                const int aq = s_kept[q], fq = s_first[aq];
+                pos += (fq < first) || (fq == first && aq < a);
+            }
+            kout[pos] = s_orig[a];
+        }
+    }
+    if (tid == 0) keep_counts[img] = nk;
+}
+
+// ------------------------------------------------------------------------------------------------
 // TP / FP matching of mAPMetric on the device (reference src/yolo/metrics.py:343-442, 568-651).
 // The reference sorts ALL predictions of a class by confidence and walks them, but a prediction only ever meets
 // the ground truths of its own image, and the kept list of an image (metrics NMS order: grouped by class,
@@ -358,9 +442,16 @@ YOLO_API int yolo_nms(const double *rec, const int32_t *counts, int N, int max_p
                       int32_t *keep_counts, yolo_stream_t stream)
 {
     if (!rec || !counts || !keep || !keep_counts || N < 0 || max_per_img <= 0) return fail(YOLO_E_ARG, "yolo_nms: bad argument");
-    if (max_per_img > 128) return fail(YOLO_E_UNSUPPORTED, "yolo_nms: max_per_img=%d > 128", max_per_img);
+    if (max_per_img > NMS_BIG_MAX) return fail(YOLO_E_UNSUPPORTED, "yolo_nms: max_per_img=%d > %d", max_per_img, NMS_BIG_MAX);
     if (variant != YOLO_NMS_INFERENCE && variant != YOLO_NMS_METRICS) return fail(YOLO_E_ARG, "yolo_nms: variant %d", variant);
     if (N == 0) return 0;
+    if (max_per_img > 128) {        // grids beyond S*S*B = 128: row-by-row sweep with a 1024-bit mask
+        if (variant == YOLO_NMS_INFERENCE)
+            hipLaunchKernelGGL(nms_big_kernel<YOLO_NMS_INFERENCE>, dim3(N), dim3(256), 0, STRM(stream), rec, counts, max_per_img, thr, keep, keep_counts);
+        else
+            hipLaunchKernelGGL(nms_big_kernel<YOLO_NMS_METRICS>, dim3(N), dim3(256), 0, STRM(stream), rec, counts, max_per_img, thr, keep, keep_counts);
+        return check_launch("yolo_nms");
+    }
     if (variant == YOLO_NMS_INFERENCE)
         hipLaunchKernelGGL(nms_kernel<YOLO_NMS_INFERENCE>, dim3(N), dim3(256), 0, STRM(stream), rec, counts, max_per_img, thr, keep, keep_counts);
     else

@@ -46,7 +46,7 @@ def main():
             print(f"  {d.class_name:12s} {d.confidence:.3f} {d.bbox}")
         if a.output_dir:
             os.makedirs(a.output_dir, exist_ok=True)
-            draw_detections(engine.load_image(path), dets).save(os.path.join(a.output_dir, os.path.basename(path)))
+            draw_detections(engine.load_image(path), dets, VOC_CLASSES, a.conf_threshold).save(os.path.join(a.output_dir, os.path.basename(path)))
 
 
 if __name__ == "__main__":

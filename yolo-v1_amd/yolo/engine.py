@@ -129,11 +129,12 @@ def _flush_caches(dev):
 
 
 # tile edge (co, px slots) of the configurations the tuner may combine
-_TILE = {1: (128, 128), 3: (128, 64), 4: (64, 128), 5: (128, 128), 10: (64, 128), 11: (256, 128), 12: (256, 256), 13: (256, 128), 14: (256, 208)}
+_TILE = {1: (128, 128), 3: (128, 64), 4: (64, 128), 5: (128, 128), 10: (64, 128), 11: (256, 128), 12: (256, 256), 13: (256, 128), 14: (256, 208),
+         15: (256, 208)}
 _TAIL_CANDIDATES = (5, 3, 4)
 # (workgroup slots of the chip, relative time of one tile) per configuration, for _default_plan: 8-wave configurations run
 # one workgroup per CU, the 4-wave ones two; times are relative to a 256x256 tile and follow the measured in-tile rates
-_TILE_COST = {12: (256, 1.00), 14: (256, 0.84), 11: (256, 0.54), 5: (512, 0.36), 3: (512, 0.20), 4: (512, 0.20)}
+_TILE_COST = {12: (256, 1.00), 14: (256, 0.80), 11: (256, 0.54), 5: (512, 0.36), 3: (512, 0.20), 4: (512, 0.20)}
 
 _SPLITK_SCRATCH: dict = {}
 
@@ -162,7 +163,9 @@ def _default_plan(d: IgemmDesc):
         tco, tpx = _TILE[hint]
         forms = [((hint, 1), tpx)]
         if hint == 14:
-            forms = [(("tile", 14, 1, 196), 196)] if M % 196 == 0 else [(("tile", 14, 1, 208), 208)]
+            nk = d.KH * d.KW * d.tap_len // 32
+            h = 15 if (nk % 2 == 0 and nk >= 4 and not d.bn_stats) else 14     # the pipelined loop where it applies
+            forms = [(("tile", h, 1, 196), 196)] if M % 196 == 0 else [(("tile", h, 1, 208), 208)]
         for plan, px in forms:
             tiles = ((d.Cout + tco - 1) // tco) * ((M + px - 1) // px)
             t = ((tiles + slots - 1) // slots) * cost
@@ -176,6 +179,8 @@ def _run_plan_igemm(L_, d: IgemmDesc, plan, inp, w, bias, aux, out, st, what):
     if d.bn_stats and (plan[0] in ("splitk", "slabs") or (isinstance(plan[0], int) and len(plan) == 4)):
         # a launch that also accumulates BatchNorm statistics must be one plain launch: keep the plan's main configuration
         plan = (plan[1], 1) if plan[0] in ("splitk", "slabs") else (plan[0], plan[1])
+    if d.bn_stats and plan[0] == "tile" and plan[1] == 15:
+        plan = ("tile", 14) + tuple(plan[2:])          # the pipelined kernel has no statistics epilogue: same tile, staggered loop
     d.tile_px, d.px_begin, d.px_end, d.skew_phases, d.skew_step = 0, 0, 0, 0, 0
     if plan[0] in ("splitk", "slabs"):
         # few-pixel deep-K layer: S workgroups per output tile into a dense fp32 scratch (atomics, or one slab per split),
@@ -262,6 +267,7 @@ def _tune(L_, d: IgemmDesc, inp, w, bias, aux, out, st, what):
     if not d.pool2:
         for o in orders:
             consider(("tile", 14, o, tile_px))
+            consider(("tile", 15, o, tile_px))      # the same tile, register-pipelined one-barrier loop
     # tail plans: the two fastest large-tile configurations, cut where their tiles stop filling whole rounds of
     # 256 (one workgroup per CU) or 512 slots, remainder with a small tile
     if times and not d.pool2:
@@ -296,7 +302,7 @@ def _tune(L_, d: IgemmDesc, inp, w, bias, aux, out, st, what):
     # fixed order, so any split count stays bit-reproducible
     if (times and not d.pool2 and not d.out_fp32 and M <= 8192 and d.KH * d.KW * d.tap_len >= 2304 and d.Cout % 8 == 0
             and d.epilogue in (EPI_NONE, EPI_BIAS, EPI_BIAS_LRELU, EPI_MUL_DLRELU)):
-        for c, S, tpv in ((11, 2, 0), (5, 2, 0), (3, 2, 0), (14, 4, tile_px), (14, 2, tile_px), (12, 4, 0), (11, 4, 0)):
+        for c, S, tpv in ((11, 2, 0), (5, 2, 0), (3, 2, 0), (14, 4, tile_px), (15, 4, tile_px), (15, 2, tile_px), (12, 4, 0), (11, 4, 0)):
             consider(("slabs", c, S, tpv))
     d.bn_stats = stats_ptr
     if not times:

@@ -133,9 +133,12 @@ class YOLOInference:
         if len(detections) == 0:
             return []
         rec = np.array([[d.class_id, d.confidence, d.bbox.x, d.bbox.y, d.bbox.width, d.bbox.height] for d in detections], np.float64)
-        if self._on_gpu() and len(rec) <= 128:
+        if self._on_gpu():
+            # a GPU model never takes a host loop silently: the device kernels cover up to 1024 boxes per image
+            # (S = 14, B = 3 -> 588); a longer list is refused by yolo_nms and that error propagates
             from . import ops
-            rec_d = torch.zeros((1, 128, 6), dtype=torch.float64, device=self.device)
+            cap = 128 if len(rec) <= 128 else max(len(rec), 129)
+            rec_d = torch.zeros((1, cap, 6), dtype=torch.float64, device=self.device)
             rec_d[0, : len(rec)] = torch.from_numpy(rec)
             cnt = torch.tensor([len(rec)], dtype=torch.int32, device=self.device)
             keep, kc = ops.nms(rec_d, cnt, thr, ops._hip.NMS_INFERENCE)
