@@ -20,6 +20,12 @@ Outputs (all small, committed):
   layers_small.npz    stock torch conv/pool/linear I/O at tiny sizes   (models.py layer hyper-params)
   backbone_full.npz   reference YOLOv1() forward on one 448x448 image with synth weights:
                       per-layer checksums + final (7,7,30)             (models.py:47-84,239-245,256-276)
+  dataset_cases.json/.npz  VOCDetectionYOLO._extract_bboxes_from_annotation / _encode_target / _parse_voc_annotation on
+                      synthetic annotation dicts (dataset.py:411-532).  src/yolo/dataset.py imports torchvision.transforms.v2,
+                      tv_tensors and datasets.VOCDetection at module scope; the three methods frozen here touch none of them
+                      (plain Python floats + torch.zeros), so the same kind of empty name holder is registered and the
+                      methods are called on an instance made WITHOUT __init__ (S, B, C, class_to_idx set as __init__ does,
+                      dataset.py:186-194).
 """
 
 from __future__ import annotations
@@ -69,6 +75,15 @@ def load_reference(ref_root: str):
     ref.metrics = _load("yolo.metrics", os.path.join(src, "metrics.py"))
     ref.models = _load("yolo.models", os.path.join(src, "models.py"))
     ref.inference = _load("yolo.inference", os.path.join(src, "inference.py"))
+    # dataset.py: more names of the absent torchvision, none of them executed by the methods frozen here
+    tv.transforms.v2 = types.ModuleType("torchvision.transforms.v2")
+    tv.tv_tensors = types.ModuleType("torchvision.tv_tensors")
+    tv.datasets = types.ModuleType("torchvision.datasets")
+    tv.datasets.VOCDetection = type("VOCDetection", (), {})
+    sys.modules.setdefault("torchvision.transforms.v2", tv.transforms.v2)
+    sys.modules.setdefault("torchvision.tv_tensors", tv.tv_tensors)
+    sys.modules.setdefault("torchvision.datasets", tv.datasets)
+    ref.dataset = _load("yolo.dataset", os.path.join(src, "dataset.py"))
     return ref
 
 
@@ -391,6 +406,63 @@ def gen_backbone(ref, out):
     return model
 
 
+# --------------------------------------------------------------------------------------------
+# dataset: annotation dict -> boxes / class ids -> (S, S, 5B + C) target
+# --------------------------------------------------------------------------------------------
+def dataset_annotations():
+    """name -> (annotation dict in the shape of torchvision's VOCDetection.parse_voc_xml, S, B)"""
+    def obj(name, xmin, ymin, xmax, ymax):
+        return {"name": name, "pose": "Unspecified", "truncated": "0", "difficult": "0",
+                "bndbox": {"xmin": str(xmin), "ymin": str(ymin), "xmax": str(xmax), "ymax": str(ymax)}}
+
+    def ann(w, h, objects):
+        return {"annotation": {"folder": "VOC2007", "filename": "000001.jpg", "size": {"width": str(w), "height": str(h), "depth": "3"},
+                               "segmented": "0", "object": objects}}
+
+    cases = {
+        "two_objects": (ann(500, 375, [obj("dog", 48, 240, 195, 371), obj("person", 8, 12, 352, 498)]), 7, 2),
+        "single_object_not_a_list": (ann(353, 500, obj("cat", 1, 1, 353, 500)), 7, 2),                 # dataset.py:436-438
+        "unknown_class_skipped": (ann(500, 375, [obj("unicorn", 10, 10, 100, 100), obj("sofa", 200, 100, 400, 300)]), 7, 2),
+        "same_cell_first_wins": (ann(448, 448, [obj("car", 100, 100, 120, 120), obj("bus", 96, 96, 126, 126), obj("bird", 300, 300, 310, 330)]), 7, 2),
+        "edges_and_clamps": (ann(500, 375, [obj("boat", 0, 0, 500, 375), obj("chair", 490, 365, 500, 375), obj("cow", 450, 0, 560, 40),
+                                            obj("train", 250, 187.5, 250, 187.5)]), 7, 2),      # full frame, corner, beyond the frame, zero size
+        "fractional_pixels": (ann(333, 250, [obj("aeroplane", 33.3, 20.25, 166.6, 199.75), obj("tvmonitor", 200.1, 10.9, 320.7, 120.2)]), 7, 2),
+        "grid14_b3": (ann(640, 480, [obj("horse", 64, 48, 320, 240), obj("sheep", 321, 241, 639, 479), obj("bottle", 600, 10, 640, 60)]), 14, 3),
+    }
+    import random
+    rnd = random.Random(7)
+    names = ["aeroplane", "bicycle", "bird", "boat", "bottle", "bus", "car", "cat", "chair", "cow", "diningtable", "dog", "horse", "motorbike",
+             "person", "pottedplant", "sheep", "sofa", "train", "tvmonitor"]
+    for k in range(6):
+        w, h = rnd.choice([(500, 375), (375, 500), (500, 333), (480, 360), (320, 240)])
+        objs = []
+        for _ in range(rnd.randint(1, 9)):
+            x0, y0 = rnd.randint(1, w - 20), rnd.randint(1, h - 20)
+            objs.append(obj(rnd.choice(names), x0, y0, rnd.randint(x0 + 1, w), rnd.randint(y0 + 1, h)))
+        cases[f"random_{k}"] = (ann(w, h, objs), 7, 2)
+    return cases
+
+
+def gen_dataset(ref, out):
+    cls = ref.dataset.VOCDetectionYOLO
+    store, meta = {}, {}
+    for name, (annotation, S, B) in dataset_annotations().items():
+        ds = object.__new__(cls)                     # no __init__: no torchvision, no files (see module docstring)
+        ds.S, ds.B, ds.C = S, B, len(cls.VOC_CLASSES)
+        ds.class_to_idx = {n: i for i, n in enumerate(cls.VOC_CLASSES)}
+        bboxes, class_ids = ds._extract_bboxes_from_annotation(annotation)
+        target = ds._parse_voc_annotation(annotation)
+        assert torch.equal(target, ds._encode_target(bboxes, class_ids))
+        meta[name] = {"annotation": annotation, "S": S, "B": B}
+        store[f"{name}__bboxes"] = np.array(bboxes, np.float64).reshape(-1, 4)
+        store[f"{name}__class_ids"] = np.array(class_ids, np.int64)
+        store[f"{name}__target"] = target.numpy()
+        print(f"  {name}: {len(class_ids)} objects, {int((target[..., 4] > 0).sum())} cells")
+    np.savez_compressed(os.path.join(out, "dataset_cases.npz"), **store)
+    with open(os.path.join(out, "dataset_cases.json"), "w") as f:
+        json.dump(meta, f, indent=1)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--ref", default="/root/reference")
@@ -398,7 +470,7 @@ def main():
     a = ap.parse_args()
     ref = load_reference(a.ref)
     only = set(a.only.split(",")) if a.only else None
-    for name, fn in (("loss", gen_loss), ("post", gen_post), ("map", gen_map), ("layers", gen_layers), ("backbone", gen_backbone)):
+    for name, fn in (("loss", gen_loss), ("post", gen_post), ("map", gen_map), ("layers", gen_layers), ("backbone", gen_backbone), ("dataset", gen_dataset)):
         if only is None or name in only:
             print(f"[{name}]")
             fn(ref, HERE)

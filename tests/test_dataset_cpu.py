@@ -93,3 +93,30 @@ def test_combined_and_factory(voc):
     assert isinstance(single, VOCDetectionYOLO) and len(single) == 1
     with pytest.raises(FileNotFoundError):
         VOCDetectionYOLO(root=voc, year="2012", image_set="test")
+
+
+def test_annotation_parsing_and_target_encoding_match_the_reference_fixture():
+    """SURVEY 8f-4 pinned to the reference: tests/golden/dataset_cases.{json,npz} hold what the reference's own
+    VOCDetectionYOLO._extract_bboxes_from_annotation / _encode_target / _parse_voc_annotation (src/yolo/dataset.py:411-532)
+    returned for these annotation dicts (make_golden.py ran them).  yolo.dataset must return the same boxes (fp64, bit for
+    bit), class ids and (S, S, 5B + C) targets (fp32, bit for bit) -- incl. a single object that is not a list, unknown
+    classes, two objects in one cell, boxes on / beyond the frame, zero-size boxes and an S = 14, B = 3 grid."""
+    import json
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    meta = json.load(open(os.path.join(here, "dataset_cases.json")))
+    g = np.load(os.path.join(here, "dataset_cases.npz"))
+    assert len(meta) >= 13
+    for name, case in meta.items():
+        ds = object.__new__(VOCDetectionYOLO)        # the methods need S, B, C and the class table only
+        ds.S, ds.B, ds.C = case["S"], case["B"], 20
+        ds.class_names = list(VOCDetectionYOLO.VOC_CLASSES) if hasattr(VOCDetectionYOLO, "VOC_CLASSES") else None
+        from yolo.dataset import VOC_CLASSES
+        ds.class_to_idx = {n: i for i, n in enumerate(VOC_CLASSES)}
+        bboxes, class_ids = ds._extract_bboxes_from_annotation(case["annotation"])
+        assert np.array_equal(np.array(bboxes, np.float64).reshape(-1, 4), g[f"{name}__bboxes"]), name
+        assert list(class_ids) == g[f"{name}__class_ids"].tolist(), name
+        want = g[f"{name}__target"]
+        for got in (ds._parse_voc_annotation(case["annotation"]), ds._encode_target(bboxes, class_ids),
+                    encode_target(bboxes, class_ids, case["S"], case["B"], 20)):
+            assert got.dtype == torch.float32 and tuple(got.shape) == want.shape, name
+            assert np.array_equal(got.numpy(), want), name

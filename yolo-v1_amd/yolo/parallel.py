@@ -113,3 +113,36 @@ class OverlappedGradAllReduce:
 
     # same entry point as GradAllReduce, so training loops can use either
     all_reduce_mean = finish
+
+
+class _Both:
+    """two reducers behind one ``all_reduce_mean`` (the overlapped one first: its collectives are already in flight)"""
+
+    def __init__(self, *reducers):
+        self.reducers = reducers
+
+    def all_reduce_mean(self) -> None:
+        for r in self.reducers:
+            r.all_reduce_mean()
+
+
+def make_grad_reducer(model: torch.nn.Module, device, group=None):
+    """The gradient averaging a training loop should use for ``model`` (call once, after the model is on its device):
+
+    * a fused YOLOv1 (``model._fusable()``) on a GPU: the whole network is one engine plan -> gradient arena +
+      ``OverlappedGradAllReduce`` (all-reduce of finished layers while backward continues, FC1's 822 MB first);
+    * ``DetectionHead`` on a ResNet trunk on a GPU: the head's plan overlapped, the trunk's parameters (which autograd
+      hands over after the head) with ``GradAllReduce``;
+    * anything else (CPU tensors, custom modules): ``GradAllReduce`` over all parameters.
+
+    The arena path OVERWRITES gradients every backward (no accumulation across backward calls), which is what the
+    reference's loop does (zero_grad before every backward, trainer.py:64)."""
+    on_gpu = torch.device(device).type == "cuda"
+    if on_gpu and hasattr(model, "_fusable") and model._fusable():
+        return OverlappedGradAllReduce(model.hip_plan(), device, group=group)
+    head = getattr(model, "head", None)
+    if on_gpu and head is not None and hasattr(head, "hip_plan"):
+        head_ids = {id(p) for p in head.parameters()}
+        rest = [p for p in model.parameters() if id(p) not in head_ids]
+        return _Both(OverlappedGradAllReduce(head.hip_plan(), device, group=group), GradAllReduce(rest, group=group))
+    return GradAllReduce(model.parameters(), group=group)

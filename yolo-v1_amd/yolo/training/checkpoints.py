@@ -4,9 +4,17 @@ checkpoints are interchangeable in both directions: ``epoch, model_state_dict, o
 
 from __future__ import annotations
 
+import os
 from pathlib import Path
 
 import torch
+
+
+def _atomic_save(data: dict, path) -> None:
+    """write next to the target and rename: a reader (or a crash) never sees a half-written checkpoint"""
+    tmp = f"{path}.tmp.{os.getpid()}"
+    torch.save(data, tmp)
+    os.replace(tmp, path)
 
 
 def _with_map(data: dict, val_losses: dict) -> dict:
@@ -19,13 +27,13 @@ def _with_map(data: dict, val_losses: dict) -> dict:
 def save_checkpoint(checkpoint_path: Path, epoch: int, model, optimizer, scheduler, train_losses: dict, val_losses: dict) -> None:
     data = {"epoch": epoch, "model_state_dict": model.state_dict(), "optimizer_state_dict": optimizer.state_dict(),
             "scheduler_state_dict": scheduler.state_dict(), "train_loss": float(train_losses["total"]), "val_loss": float(val_losses["total"])}
-    torch.save(_with_map(data, val_losses), checkpoint_path)
+    _atomic_save(_with_map(data, val_losses), checkpoint_path)
     print(f"  checkpoint saved: {checkpoint_path}")
 
 
 def save_best_model(checkpoint_path: Path, epoch: int, model, optimizer, val_losses: dict, metric_name: str, metric_value: float) -> None:
     data = {"epoch": epoch, "model_state_dict": model.state_dict(), "optimizer_state_dict": optimizer.state_dict(), "val_loss": float(val_losses["total"])}
-    torch.save(_with_map(data, val_losses), checkpoint_path)
+    _atomic_save(_with_map(data, val_losses), checkpoint_path)
     print(f"  new best model ({metric_name}={metric_value:.4f}) saved: {checkpoint_path}")
 
 

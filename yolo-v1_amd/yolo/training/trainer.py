@@ -16,7 +16,7 @@ import torch
 import torch.distributed as dist
 
 from ..metrics import evaluate_model
-from ..parallel import GradAllReduce
+from ..parallel import make_grad_reducer
 from .checkpoints import save_best_map_model, save_best_model, save_checkpoint
 
 _PARTS = ("total", "coord", "conf_obj", "conf_noobj", "class")
@@ -33,7 +33,14 @@ def train_epoch(model, dataloader, criterion, optimizer, device, epoch: int, wri
     sums = dict.fromkeys(_PARTS, 0.0)
     n = 0
     fused_clip = getattr(optimizer, "max_grad_norm", None) is not None
-    allreduce = GradAllReduce(model.parameters()) if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1 else None
+    # data parallel: the reducer is chosen once per model (it may attach a gradient arena to the model's plan) -- on a GPU
+    # the all-reduce overlaps the backward pass, the path bench.py measures
+    allreduce = None
+    if dist.is_available() and dist.is_initialized():
+        allreduce = getattr(model, "_yolo_grad_reducer", None)
+        if allreduce is None:
+            allreduce = make_grad_reducer(model, device)
+            model._yolo_grad_reducer = allreduce
     t0 = time.time()
     for batch_idx, (images, targets) in enumerate(dataloader):
         images = images.to(device, non_blocking=True)
@@ -105,15 +112,24 @@ def train(model, train_loader, val_loader, criterion, optimizer, scheduler, devi
                 writer.add_scalar(f"epoch/train_{k}", tr[k], epoch)
                 writer.add_scalar(f"epoch/val_{k}", va[k], epoch)
             writer.add_scalar("epoch/lr", lr, epoch)
-        save_checkpoint(checkpoint_dir / "yolo_latest.pth", epoch, model, optimizer, scheduler, tr, va)
-        if epoch % save_frequency == 0:
-            save_checkpoint(checkpoint_dir / f"yolo_epoch_{epoch}.pth", epoch, model, optimizer, scheduler, tr, va)
+        # checkpoints are written by rank 0 only (every rank holds the same parameters and optimizer state; BatchNorm running
+        # statistics are per rank -- there is no SyncBN, as in the reference -- and rank 0's are the ones saved); the other
+        # ranks wait, so that nobody runs ahead of a file that a later --resume on all ranks would read
+        writer_rank = not (dist.is_available() and dist.is_initialized()) or dist.get_rank() == 0
+        if writer_rank:
+            save_checkpoint(checkpoint_dir / "yolo_latest.pth", epoch, model, optimizer, scheduler, tr, va)
+            if epoch % save_frequency == 0:
+                save_checkpoint(checkpoint_dir / f"yolo_epoch_{epoch}.pth", epoch, model, optimizer, scheduler, tr, va)
         if va["total"] < best_val:
             best_val = va["total"]
-            save_best_model(checkpoint_dir / "yolo_best.pth", epoch, model, optimizer, va, "val_loss", best_val)
+            if writer_rank:
+                save_best_model(checkpoint_dir / "yolo_best.pth", epoch, model, optimizer, va, "val_loss", best_val)
         if "mAP50:95" in va and va["mAP50:95"] > best_map:
             best_map = va["mAP50:95"]
-            save_best_map_model(checkpoint_dir / "yolo_best_map.pth", epoch, model, optimizer, va, best_map)
+            if writer_rank:
+                save_best_map_model(checkpoint_dir / "yolo_best_map.pth", epoch, model, optimizer, va, best_map)
+        if dist.is_available() and dist.is_initialized():
+            dist.barrier()
         final_train = tr["total"]
     out = {"best_val_loss": best_val, "final_train_loss": final_train}
     if best_map > 0:
