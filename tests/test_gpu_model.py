@@ -44,40 +44,153 @@ def test_forward_matches_reference_fixture(model, golden):
     model.cpu()
 
 
-def test_train_step_gradients_vs_cpu_autograd(model):
-    """loss + backward on 2 images: every parameter gradient vs torch CPU autograd (fp32)."""
+def test_train_step_gradients_vs_gate_forced_cpu_autograd(model):
+    """loss + backward on 2 images: EVERY parameter gradient vs torch CPU autograd on a network whose LeakyReLU gates and
+    max-pool selections are taken from the activations the GPU pass stored.  Free-running fp32 autograd differs from a bf16
+    pipeline mainly through gates of pre-activations ~0 that flip (each flip changes a unit's gradient x10), which says
+    nothing about the kernels; with the gates forced, the remaining difference is bf16 storage of activations / gradients
+    and accumulation order, and the bound is tight: relative L2 error < 2 % per parameter tensor
+    (reference: src/yolo/models.py:256-276, src/yolo/loss.py:87-172)."""
     import copy
+    import torch.nn as nn
+    import torch.nn.functional as F
     from yolo import YOLOLoss
+    from test_gpu_layers import _bf
     N = 2
     x = torch.from_numpy(synth.synth_images(N, 3))
     t = torch.from_numpy(synth.synth_targets(N, 21, max_obj=4))
-    from test_gpu_layers import bf16_faithful
-    ref = copy.deepcopy(model).cpu().eval()     # eval: dropout off on both sides
-    # stock torch.nn with the GPU path's storage precision (bf16 weights / stored activations)
-    ref_net = torch.nn.Sequential(bf16_faithful(ref.backbone.features), bf16_faithful(ref.head))
     crit = YOLOLoss()
-    lr, _ = crit(ref_net(x.to(torch.bfloat16).float()).view(-1, 7, 7, 30), t)
+    m = model.cuda().eval()                      # eval: dropout off
+    plan = m.hip_plan()
+    plan.debug_keep = True
+    try:
+        m.zero_grad()
+        lg, _ = crit(m(x.cuda()), t.cuda())
+        lg.backward()
+        torch.cuda.synchronize()
+        ws, fc_saved = plan.last
+    finally:
+        plan.debug_keep = False
+        plan.last = None
+
+    def nchw(act):
+        return act.interior().float().cpu().permute(0, 3, 1, 2).contiguous()
+
+    def q(v):                                    # straight-through bf16 rounding = a stored activation
+        return v + (_bf(v) - v).detach()
+
+    ref = copy.deepcopy(model).cpu().eval()
+    mods = list(ref.backbone.features) + list(ref.head)
+    with torch.no_grad():
+        for mod in mods:
+            if isinstance(mod, (nn.Conv2d, nn.Linear)):
+                mod.weight.copy_(_bf(mod.weight))
+    h = _bf(x)
+    li = 0                                       # index into plan.layers (conv | pool | flatten | fc), mods carries the LeakyReLUs too
+    i = 0
+    while i < len(mods):
+        mod = mods[i]
+        if isinstance(mod, nn.Conv2d):
+            z = mod(h)
+            gate = torch.where(nchw(ws["acts"][li]) > 0, 1.0, 0.1)           # the GPU's LeakyReLU gates of this layer
+            h = q(z * gate)
+            i += 2
+            li += 1
+        elif isinstance(mod, nn.MaxPool2d):
+            _, idx = F.max_pool2d(nchw(ws["acts"][li - 1]), 2, 2, return_indices=True)   # the GPU's arg-maxes
+            h = h.flatten(2).gather(2, idx.flatten(2)).view(idx.shape)
+            i += 1
+            li += 1
+        elif isinstance(mod, nn.Flatten):
+            h = mod(h)
+            i += 1
+            li += 1
+        elif isinstance(mod, nn.Linear):
+            z = mod(h)
+            if i + 1 < len(mods) and isinstance(mods[i + 1], nn.LeakyReLU):
+                y1 = fc_saved[li][1].float().cpu()
+                h = q(z * torch.where(y1 > 0, 1.0, 0.1))
+                i += 2
+            else:
+                h = z
+                i += 1
+            li += 1
+        else:                                    # Dropout in eval mode
+            i += 1
+    lr, _ = crit(h.view(-1, 7, 7, 30), t)
     lr.backward()
-    m = model.cuda().eval()
-    m.zero_grad()
-    lg, dg = crit(m(x.cuda()), t.cuda())
-    lg.backward()
-    assert abs(lg.item() - lr.item()) < 0.05 * abs(lr.item())
+    assert abs(lg.item() - lr.item()) < 0.02 * abs(lr.item()), (lg.item(), lr.item())
     report, bad = [], []
     for (n1, p1), (_, p2) in zip(m.named_parameters(), ref.named_parameters()):
         assert p1.grad is not None, n1
         g1, g2 = p1.grad.double().cpu().flatten(), p2.grad.double().flatten()
-        cos = (torch.dot(g1, g2) / (g1.norm() * g2.norm() + 1e-30)).item()
         rel = ((g1 - g2).norm() / (g2.norm() + 1e-30)).item()
-        report.append(f"{n1:34s} cos {cos:.5f} rel {rel:.4f} |ref| {g2.norm().item():.3e}")
-        # end-to-end agreement is limited by LeakyReLU gates / pool arg-maxes that flip when a
-        # pre-activation ~0 is accumulated in a different order (each flip changes that unit's
-        # gradient x10); the kernels themselves are checked layer by layer below.
-        if not (cos > 0.9 and rel < 0.4):
+        report.append(f"{n1:34s} rel {rel:.4f} |ref| {g2.norm().item():.3e}")
+        if not rel < 0.02:
             bad.append(n1)
     model.cpu()
     print("\n".join(report))
     assert not bad, "\n".join(report)
+
+
+def test_one_plan_serves_several_input_sizes():
+    """sizes A, B, A through ONE backbone plan, forward and backward: the layer geometry belongs to the workspace of a call,
+    not to the plan (a standalone YOLOv1Backbone takes any resolution, as the reference's does).  The third call must
+    reproduce the first bit for bit in the forward and to fp32-atomic order in the gradients; both sizes agree with stock
+    torch; and a forward at size B BETWEEN a training forward at size A and its backward must not disturb that backward."""
+    import copy
+    from test_gpu_layers import _bf, _close, bf16_faithful
+    from yolo import YOLOv1Backbone
+    torch.manual_seed(3)
+    bb = YOLOv1Backbone()
+    ref = bf16_faithful(copy.deepcopy(bb).features)
+    bb = bb.cuda().train()
+    xa = torch.randn(2, 3, 128, 128)
+    xb = torch.randn(1, 3, 192, 160)
+
+    def run(x):
+        bb.zero_grad()
+        y = bb(x.cuda())
+        gy = torch.ones_like(y) / y.numel()
+        y.backward(gy)
+        return y.detach().clone(), [p.grad.detach().clone() for p in bb.parameters()]
+
+    ya, ga = run(xa)
+    yb, gb = run(xb)
+    ya2, ga2 = run(xa)
+    assert ya.shape == (2, 1024, 2, 2) and yb.shape == (1, 1024, 3, 3)
+    assert torch.equal(ya, ya2)
+    for a, b in zip(ga, ga2):
+        torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-7)
+    for x, y in ((xa, ya), (xb, yb)):
+        _close(y, _bf(ref(_bf(x))), 6.0, f"backbone forward at {tuple(x.shape)}")
+    # interleaved: forward A (training), forward B (no grad), backward A
+    bb.zero_grad()
+    y = bb(xa.cuda())
+    with torch.no_grad():
+        bb(xb.cuda())
+    y.backward(torch.ones_like(y) / y.numel())
+    for a, p in zip(ga, bb.parameters()):
+        torch.testing.assert_close(p.grad, a, rtol=1e-4, atol=1e-7)
+
+
+def test_shape_errors_are_raised_not_read_out_of_bounds(model):
+    """the library cannot know buffer extents, so the host side must refuse what the reference refuses (stock nn.Linear /
+    tensor indexing raise there): a 224 x 224 batch into the 448 x 448 head, a 4-channel image, YOLOLoss with the wrong grid."""
+    from yolo import YOLOLoss
+    m = model.cuda().eval()
+    with torch.no_grad():
+        with pytest.raises(RuntimeError, match="cannot be multiplied|does not match"):
+            m(torch.zeros(2, 3, 224, 224, device="cuda"))
+        with pytest.raises(RuntimeError, match="expected input"):
+            m(torch.zeros(2, 4, 448, 448, device="cuda"))
+        assert m(torch.zeros(1, 3, 448, 448, device="cuda")).shape == (1, 7, 7, 30)      # the plan is still usable
+    pred = torch.zeros(2, 7, 7, 30, device="cuda")
+    with pytest.raises(RuntimeError, match="must both be"):
+        YOLOLoss(S=14)(pred, pred)
+    with pytest.raises(RuntimeError, match="must both be"):
+        YOLOLoss()(pred, torch.zeros(2, 7, 7, 25, device="cuda"))
+    model.cpu()
 
 
 def test_loss_decreases_with_adam(model):

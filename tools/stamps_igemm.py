@@ -42,6 +42,22 @@ for item in synth.YOLOV1_BACKBONE_CFG:
     buf = torch.zeros(512 * 64, dtype=torch.int64, device=dev)
     for _ in range(20):
         check(lib().yolo_igemm(ctypes.byref(d), x.p, ptr(w), ptr(b), None, y.p, stream()))
+    if int(hint) == 15:
+        # the pipelined kernel stamps its sections, not a K iteration
+        check(lib().yolo_debug_stamps(ptr(buf), 0))
+        for _ in range(3):
+            check(lib().yolo_igemm(ctypes.byref(d), x.p, ptr(w), ptr(b), None, y.p, stream()))
+        torch.cuda.synchronize()
+        st = buf.cpu().view(512, 8, 8).double()
+        ok = st[:, 0, 4] > 0
+        seg = (st[:, :, 1:5] - st[:, :, 0:4])[ok].reshape(-1, 4)
+        t0 = st[ok][:, :, 0].min()
+        print(f"layer {layer} hint 15:{tpx or 0}: {int(ok.sum())} workgroups stamped; medians in cycles")
+        print("  table %6.0f | first stage %6.0f | K loop (%d steps) %7.0f = %5.0f / step | epilogue %6.0f | total %7.0f" % (
+            seg[:, 0].median(), seg[:, 1].median(), nk, seg[:, 2].median(), seg[:, 2].median() / nk, seg[:, 3].median(), seg.sum(1).median()))
+        print("  first workgroup starts at 0, the last stamped one at %.0f, the last one ends at %.0f cycles" % ((st[ok][:, :, 0].max() - t0).item(), (st[ok][:, :, 4].max() - t0).item()))
+        check(lib().yolo_debug_stamps(None, 0))
+        sys.exit(0)
     for it in (nk // 2, nk // 2 + 1, nk // 3):
         check(lib().yolo_debug_stamps(ptr(buf), it))
         for _ in range(3):

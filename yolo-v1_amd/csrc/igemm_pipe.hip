@@ -56,6 +56,13 @@ __global__ void __launch_bounds__(pipe::NTHR, 2) igemm_pipe_kernel(const IgemmPa
     const int wco = wave % WCO, grp = wave / WCO;          // grp 0: pixel columns 0..6, grp 1: 7..12
     const int px_lo = grp * NT0 * 16;
 
+#ifdef IGEMM_STAMPS
+    long tstamp[5];
+    tstamp[0] = __builtin_amdgcn_s_memtime();
+#define PSTAMP(i) do { __builtin_amdgcn_sched_barrier(0); tstamp[i] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define PSTAMP(i) do { } while (0)
+#endif
     // start skew (see igemm.hip)
     if (p.skew_phases > 1 && gridDim.x * gridDim.y > 256 && blockIdx.y == 0 && blockIdx.x < 256) {
         const int ph = (blockIdx.x >> 3) % p.skew_phases;
@@ -92,6 +99,7 @@ __global__ void __launch_bounds__(pipe::NTHR, 2) igemm_pipe_kernel(const IgemmPa
     }
     __syncthreads();
 
+    PSTAMP(1);
     // LDS-DMA pieces of this wave: weight pieces q = wave, wave + 8; pixel pieces likewise.  Lane -> (row, 16-B chunk) through the
     // inverse swizzle (the DMA writes lane-linear), as a 32-bit BYTE offset from the operand's base pointer.
     unsigned a_voff[2], b_voff[2];
@@ -167,6 +175,7 @@ __global__ void __launch_bounds__(pipe::NTHR, 2) igemm_pipe_kernel(const IgemmPa
     else wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
+    PSTAMP(2);
 
     auto run = [&](auto ntc) {
         constexpr int NTG = decltype(ntc)::value;
@@ -258,6 +267,7 @@ __global__ void __launch_bounds__(pipe::NTHR, 2) igemm_pipe_kernel(const IgemmPa
 
     wait_vmcnt<0>();
     __syncthreads();  // all MFMA operand reads done before the stage area is reused for the epilogue
+    PSTAMP(3);
 
     // ---- epilogue (as igemm.hip, uneven split): two passes -- group A's 112 pixels, group B's 96 -- through an fp32 slab
     // [px][co] in LDS, then 16-B coalesced stores along the channel axis with the layer's epilogue applied
@@ -342,6 +352,15 @@ __global__ void __launch_bounds__(pipe::NTHR, 2) igemm_pipe_kernel(const IgemmPa
             }
         }
     }
+#ifdef IGEMM_STAMPS
+    // diagnostic build: kernel start | table built | stage 0 visible | K loop done | end, per wave of the first 512 workgroups
+    if (p.dbg && lane == 0 && blockIdx.x < 512 && blockIdx.y == 0) {
+        tstamp[4] = __builtin_amdgcn_s_memtime();
+#pragma unroll
+        for (int i = 0; i < 5; ++i) p.dbg[((long)blockIdx.x * 8 + wave) * 8 + i] = tstamp[i];
+    }
+#endif
+#undef PSTAMP
 }
 
 int igemm_pipe_launch(const IgemmParams &p, int splits, hipStream_t s)

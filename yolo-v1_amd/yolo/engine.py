@@ -879,6 +879,14 @@ class Plan:
             return g.img_stride, g.row_stride, g.px_stride, g.interior_off()
         return g.img_stride, 2 * g.row_stride, 2 * g.px_stride, g.interior_off()
 
+    @staticmethod
+    def _wgrad_desc(L: Layer, g: Act, xin: Act, N: int) -> WgradDesc:
+        """yolo_wgrad problem of conv layer L over N images of the gradient buffer g / the input buffer xin"""
+        if L.Hout >= 2 and L.Wout >= 2 and (L.stride > 1 or g.Hp * g.Wp >= 1.12 * L.Hout * L.Wout):
+            return WgradDesc(N * L.Hout * L.Wout, g.px_stride, xin.px_stride, L.Cout, L.Cin, L.K, L.K, L.pad, xin.row_stride, 0, 0, 0,
+                             L.Wout, L.Hout, g.Hp * g.Wp, g.Wp * L.stride, L.stride, g.halo * g.Wp + g.halo)
+        return WgradDesc(N * g.Hp * g.Wp, g.px_stride, xin.px_stride, L.Cout, L.Cin, L.K, L.K, L.pad, xin.row_stride, 0, 0)
+
     def backward(self, saved, gout: torch.Tensor, need_gx: bool):
         """gout: gradient of the plan output (same shape as forward's out).  Returns (gx or None, [param grads])."""
         L_ = lib()
@@ -1082,11 +1090,7 @@ class Plan:
                     # zero-stuffed -- gradient buffer, whose geometry the input buffer shares slot for slot)
                     # (measured: worth it from 28x28 down and for stride 2; at 56x56 and above the halo is < 8 % of the slots
                     # and the per-row coordinate arithmetic costs more than it saves)
-                    if L.Hout >= 2 and L.Wout >= 2 and (L.stride > 1 or g.Hp * g.Wp >= 1.12 * L.Hout * L.Wout):
-                        wd = WgradDesc(N * L.Hout * L.Wout, g.px_stride, xin.px_stride, L.Cout, L.Cin, L.K, L.K, L.pad, xin.row_stride, 0, 0, 0,
-                                       L.Wout, L.Hout, g.Hp * g.Wp, g.Wp * L.stride, L.stride, g.halo * g.Wp + g.halo)
-                    else:
-                        wd = WgradDesc(g.slots, g.px_stride, xin.px_stride, L.Cout, L.Cin, L.K, L.K, L.pad, xin.row_stride, 0, 0)
+                    wd = self._wgrad_desc(L, g, xin, N)
                     with _timed(f"conv{li}.wgrad", "wgrad", 2.0 * N * L.Hout * L.Wout * L.Cout * L.Cin * L.K * L.K):
                         check(L_.yolo_wgrad(ctypes.byref(wd), xin.p, g.p, ptr(dwp), ptr(db), st), f"wgrad conv{li}")
                 if not stem_direct:
