@@ -342,6 +342,10 @@ int yolo_cast_bf16_to_f32(const void *x_bf16, long n, float *y, yolo_stream_t st
 /* y = lrelu(x + bias[col]) over [R][Ccols] fp32, bf16 and/or fp32 outputs (finishes a split-K Linear). */
 int yolo_bias_lrelu_rows(const float *x, const float *bias, int R, int Ccols, float slope,
                          void *y_bf16, float *y_f32, yolo_stream_t stream);
+/* the same finishing pass for a Linear layer whose split_k workgroups STORED their partial results as slabs
+ * (yolo_igemm_desc.split_slabs): x = fp32 [slabs][R][Ccols], added in the fixed order 0, 1, .. -> bit-reproducible forward. */
+int yolo_bias_lrelu_rows_slabs(const float *x, int slabs, const float *bias, int R, int Ccols, float slope,
+                               void *y_bf16, float *y_f32, yolo_stream_t stream);
 
 /* y[r][0..ld) = bf16( x[r][c] * (mask ? (mask[r][c] ? scale : 0) : 1) * (act ? (act[r][c] > 0 ? 1 : slope) : 1) ),
  * columns Cc..ld-1 zero.  x fp32 [R][Cc], mask u8 [R][Cc], act bf16 [R][Cc].  Backward of

@@ -483,7 +483,10 @@ def test_frozen_resnet_backbone_in_training_mode():
     assert int(g.backbone.extractor[7][2].bn3.num_batches_tracked) == 1
     # one training step: gradients reach the head only, and equal the CPU head's gradients for the same features
     crit = YOLOLoss()
-    loss_g, _ = crit(g(x.cuda()), tgt.cuda())
+    pred_g = g(x.cuda())
+    seen = []
+    pred_g.register_hook(lambda gr: seen.append(gr.detach().cpu().clone()))     # dL/dpred as it enters the head's backward
+    loss_g, _ = crit(pred_g, tgt.cuda())
     loss_g.backward()
     assert all(p.grad is None for p in g.backbone.parameters())
     feats = g.backbone._plan.forward_batch_stats(x.cuda()).cpu()
@@ -501,12 +504,17 @@ def test_frozen_resnet_backbone_in_training_mode():
         h = mod(h)
         if isinstance(mod, torch.nn.LeakyReLU):
             h = q(h)
-    loss_c, _ = crit(h.view(-1, 7, 7, 30), tgt)
-    loss_c.backward()
+    out_c = h.view(-1, 7, 7, 30)
+    loss_c, _ = crit(out_c, tgt)
     assert abs(loss_g.item() - loss_c.item()) < 0.02 * abs(loss_c.item())
+    # the loss gradient is taken from the GPU pass (teacher forcing): on random-init predictions the loss's choice of the
+    # responsible box (arg-max of two IoUs that are both ~0, src/yolo/loss.py:110) flips under a 1 % perturbation of the
+    # prediction and changes dL/dpred by tens of per cent -- a property of the loss, checked on its own in test_gpu_loss.py
+    out_c.backward(seen[0])
     hg = dict(g.head.named_parameters())
+    report = {n: _rel(hg[n].grad, pc.grad) for n, pc in m.head.named_parameters()}
     for n, pc in m.head.named_parameters():
-        assert hg[n].grad is not None and _rel(hg[n].grad, pc.grad) < 0.08, (n, _rel(hg[n].grad, pc.grad))
+        assert hg[n].grad is not None and report[n] < 0.05, report
 
 
 def test_gradient_arena_equals_autograd_path(model):

@@ -706,8 +706,8 @@ YOLO_API int yolo_igemm(const yolo_igemm_desc *d, const void *in, const void *w,
     if (d->epilogue < 0 || d->epilogue > YOLO_EPI_BIAS_ADD_LRELU) return fail(YOLO_E_ARG, "yolo_igemm: epilogue %d", d->epilogue);
     const int splits = d->split_k > 1 ? d->split_k : 1;
     if (splits > 1 && (!d->out_fp32 || d->epilogue != YOLO_EPI_NONE)) return fail(YOLO_E_ARG, "yolo_igemm: split_k needs fp32 output and EPI_NONE");
-    if (d->split_slabs && splits > 1 && (d->out_px_stride != d->Cout || d->out_off != 0 || d->out_row_stride != d->Wo * d->Cout
-                                         || d->out_img_stride != (int64_t)d->Ho * d->Wo * d->Cout))
+    if (d->split_slabs && splits > 1 && (d->out_off != 0 || (d->Wo > 1 && d->out_px_stride != d->Cout) || (d->Ho > 1 && d->out_row_stride != d->Wo * d->Cout)
+                                         || (d->N > 1 && d->out_img_stride != (int64_t)d->Ho * d->Wo * d->Cout)))
         return fail(YOLO_E_ARG, "yolo_igemm: split_slabs needs the dense [N*Ho*Wo][Cout] output addressing");
     if (d->tile_px < 0) return fail(YOLO_E_ARG, "yolo_igemm: tile_px %d", d->tile_px);
     if (!d->out_fp32 && ((d->Cout & 7) || (d->out_off & 7) || (d->out_px_stride & 7) || (d->out_row_stride & 7) || (d->out_img_stride & 7)))

@@ -404,13 +404,16 @@ __global__ void cast_bf16_f32_kernel(const bf16_t *__restrict__ x, long n, float
         for (long k = i; k < n; ++k) y[k] = bf16_to_f32(x[k]);
     }
 }
-__global__ void bias_lrelu_rows_kernel(const float *__restrict__ x, const float *__restrict__ bias, int R, int Cc, float slope,
+__global__ void bias_lrelu_rows_kernel(const float *__restrict__ x, int slabs, const float *__restrict__ bias, int R, int Cc, float slope,
                                        bf16_t *__restrict__ yb, float *__restrict__ yf)
 {
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= (long)R * Cc) return;
+    const long total = (long)R * Cc;
+    if (idx >= total) return;
     const int c = (int)(idx % Cc);
-    float v = x[idx] + (bias ? bias[c] : 0.0f);
+    float v = x[idx];
+    for (int s = 1; s < slabs; ++s) v += x[(long)s * total + idx];      // fixed order: independent of which split finished first
+    v += bias ? bias[c] : 0.0f;
     v = v > 0.0f ? v : v * slope;
     if (yb) yb[idx] = f32_to_bf16(v);
     if (yf) yf[idx] = v;
@@ -613,11 +616,16 @@ YOLO_API int yolo_cast_bf16_to_f32(const void *x, long n, float *y, yolo_stream_
     return check_launch("yolo_cast_bf16_to_f32");
 }
 
+YOLO_API int yolo_bias_lrelu_rows_slabs(const float *x, int slabs, const float *bias, int R, int Cc, float slope, void *yb, float *yf, yolo_stream_t stream)
+{
+    if (!x || (!yb && !yf) || R <= 0 || Cc <= 0 || slabs < 1) return fail(YOLO_E_ARG, "yolo_bias_lrelu_rows: bad argument");
+    hipLaunchKernelGGL(bias_lrelu_rows_kernel, dim3(nblk((long)R * Cc, 256)), dim3(256), 0, STRM(stream), x, slabs, bias, R, Cc, slope, (bf16_t *)yb, yf);
+    return check_launch("yolo_bias_lrelu_rows");
+}
+
 YOLO_API int yolo_bias_lrelu_rows(const float *x, const float *bias, int R, int Cc, float slope, void *yb, float *yf, yolo_stream_t stream)
 {
-    if (!x || (!yb && !yf) || R <= 0 || Cc <= 0) return fail(YOLO_E_ARG, "yolo_bias_lrelu_rows: bad argument");
-    hipLaunchKernelGGL(bias_lrelu_rows_kernel, dim3(nblk((long)R * Cc, 256)), dim3(256), 0, STRM(stream), x, bias, R, Cc, slope, (bf16_t *)yb, yf);
-    return check_launch("yolo_bias_lrelu_rows");
+    return yolo_bias_lrelu_rows_slabs(x, 1, bias, R, Cc, slope, yb, yf, stream);
 }
 
 YOLO_API int yolo_scale_rows_to_bf16(const float *x, const unsigned char *mask, float scale, const void *act, float slope, int R, int Cc, int ld, void *y,

@@ -823,13 +823,16 @@ class Plan:
                 splits = max(1, min(32 if d.w_blocked else 48, nk // 16)) if K >= 4096 else 1
                 b = L.bias.detach()
                 if splits > 1:
-                    acc = torch.zeros((N, L.Cout), dtype=torch.float32, device=dev)
-                    d.epilogue, d.split_k = EPI_NONE, splits
+                    # every K split STORES its partial [N][Cout] result as a slab; the finishing pass adds the slabs in fixed
+                    # order -> the forward is bit-reproducible (fp32 atomics of 32 splits were not) and needs no zero fill
+                    acc = _splitk_scratch(splits * N * L.Cout, zero=False)
+                    d.epilogue, d.split_k, d.split_slabs = EPI_NONE, splits, 1
                     with _timed(f"fc{li}", "igemm", 2.0 * N * L.Cout * L.Cin):
                         _igemm(L_, d, ptr(xin), ptr(wf), None, None, ptr(acc), st, f"igemm fc{li}")
                     yb = torch.empty((N, L.Cout), dtype=torch.bfloat16, device=dev) if not last else None
                     yf = torch.empty((N, L.Cout), dtype=torch.float32, device=dev) if last else None
-                    check(L_.yolo_bias_lrelu_rows(ptr(acc), ptr(b), N, L.Cout, self.SLOPE if L.lrelu else 1.0, ptr(yb), ptr(yf), st), "bias_lrelu_rows")
+                    check(L_.yolo_bias_lrelu_rows_slabs(ptr(acc), splits, ptr(b), N, L.Cout, self.SLOPE if L.lrelu else 1.0, ptr(yb), ptr(yf), st),
+                          "bias_lrelu_rows")
                 else:
                     yf = torch.empty((N, L.Cout), dtype=torch.float32, device=dev)
                     d.epilogue, d.split_k = (EPI_BIAS_LRELU if L.lrelu else EPI_BIAS), 1
