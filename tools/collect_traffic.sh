@@ -8,7 +8,7 @@ OUT=${1:-gpurun_out/traffic}
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c --output-format csv -d "$OUT" -o pmc_$c -- python3 bench.py --steps 3 --warmup 1 --no-train --no-nms --no-cpu > "$OUT/bench_$c.json" 2> "$OUT/err_$c.log"
+  rocprofv3 --pmc $c --output-format csv -d "$OUT" -o pmc_$c -- python3 bench.py --steps 3 --warmup 1 --no-train --no-nms --no-cpu --no-resnet > "$OUT/bench_$c.json" 2> "$OUT/err_$c.log"
 done
 python3 tools/traffic_summary.py "$OUT" > "$OUT/igemm_traffic.json"
 cat "$OUT/igemm_traffic.json"

@@ -8,8 +8,10 @@ rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 marks = [i for i, r in enumerate(rows) if r["Kernel_Name"].startswith("yolo::sumsq_kernel(")]
 assert len(marks) >= 2, "marker launches not found"
 seg = rows[marks[0] + 1: marks[1]]
-ig = [r for r in seg if "igemm_kernel" in r["Kernel_Name"]]
+def _ig(name):
+    return "igemm_kernel" in name or "igemm_pipe_kernel" in name
+ig = [r for r in seg if _ig(r["Kernel_Name"])]
 dur = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6 for r in ig]
-other = sum((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6 for r in seg if "igemm_kernel" not in r["Kernel_Name"])
+other = sum((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6 for r in seg if not _ig(r["Kernel_Name"]))
 print(f"roofline pass: {len(ig)} igemm launches in 3 forward passes ({len(ig) // 3} per pass); mean {sum(dur) / len(dur):.4f} ms per launch; "
       f"igemm {sum(dur) / 3:.3f} ms + other kernels {other / 3:.3f} ms per forward pass")
