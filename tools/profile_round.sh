@@ -1,0 +1,24 @@
+#!/bin/bash
+# One profile set of a round, on the GPU box from the repo root:  bash tools/profile_round.sh r2_v1
+#   1. rocprofv3 --kernel-trace --stats of the default bench.py line  -> profiles/<tag>_bench_kernel_stats.{csv,txt}, <tag>_bench.json,
+#      <tag>_roofline_pass_from_trace.txt (kernel-trace durations of the roofline pass vs bench.py's own HIP events)
+#   2. HBM traffic of the forward's igemm launches (two separate --pmc passes) -> profiles/<tag>_igemm_traffic.json
+#   3. SQ counters (MFMA busy, LDS conflicts, issue stalls; two --pmc passes)   -> profiles/<tag>_igemm_sq_pmc.txt
+# Counter passes never run together with tracing (MI355X_MICROARCH.md, rocprofv3 PMC).
+set -e
+TAG=${1:-r2_v1}
+OUT=gpurun_out/prof_$TAG
+mkdir -p "$OUT" profiles
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT" -o bench -- python3 bench.py --no-cpu > "$OUT/bench.json" 2> "$OUT/bench.err"
+cp "$OUT/bench.json" profiles/${TAG}_bench.json
+cp "$OUT"/bench_kernel_stats.csv profiles/${TAG}_bench_kernel_stats.csv
+python3 tools/kstats.py "$OUT"/bench_kernel_stats.csv 45 > profiles/${TAG}_bench_kernel_stats.txt
+python3 tools/trace_roofline.py "$OUT"/bench_kernel_trace.csv > profiles/${TAG}_roofline_pass_from_trace.txt
+cat profiles/${TAG}_roofline_pass_from_trace.txt
+bash tools/collect_traffic.sh "$OUT/traffic" > /dev/null
+cp "$OUT/traffic/igemm_traffic.json" profiles/${TAG}_igemm_traffic.json
+cat profiles/${TAG}_igemm_traffic.json
+bash tools/pmc_igemm.sh "$OUT/pmc" > profiles/${TAG}_igemm_sq_pmc.txt
+tail -20 profiles/${TAG}_igemm_sq_pmc.txt
+python3 bench.py --no-cpu > profiles/${TAG}_bench_unprofiled.json 2> /dev/null
