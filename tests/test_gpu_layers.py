@@ -363,7 +363,7 @@ def test_fc_dgrad_behind_flatten_matches_cpu():
         _close(a, b, 3.0, n, frac=0.01)
 
 
-@pytest.mark.parametrize("hint", [1, 2, 3, 4, 5, 6, 10, 11, 12, 13, 14, (14, 196), (14, 49), (12, 196), (5, 98), 15, (15, 196), (15, 49)])
+@pytest.mark.parametrize("hint", [1, 2, 3, 4, 5, 6, 10, 11, 12, 13, 14, (14, 196), (14, 49), (12, 196), (5, 98), 15, (15, 196), (15, 49), 16, (16, 112), 17, (17, 196), 18, (18, 100)])
 def test_every_tile_configuration(hint):
     """the same 3x3 / 1x1 chain through each yolo_igemm tile configuration (128x128, 256x128 8-wave
     3-stage ring, 128x64, 64x128, 256x208 with the uneven staggered split), forward and data-gradient, with ragged pixel
@@ -507,3 +507,45 @@ def test_fused_pool_epilogue_equals_separate_pool():
         finally:
             engine.FUSE_POOL = True
     assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("W,cin,cout", [(112, 64, 192), (56, 64, 320), (28, 128, 512), (56, 128, 128)])
+def test_pool_fused_into_the_pipelined_tiles(W, cin, cout):
+    """conv -> LeakyReLU -> MaxPool2d(2,2) through the 224-pixel tiles of the register-pipelined kernels (tile_hint 16 / 18):
+    rows of 112 (two half rows per pixel group), 56 and 28 pixels -- inference (pooled map only) and training (pool2 = 2: the
+    un-pooled activation is written as well) equal the un-fused launches bit for bit, forward AND backward."""
+    from yolo import engine
+    torch.manual_seed(9)
+    mods = nn.Sequential(nn.Conv2d(cin, cout, 3, 1, 1), nn.LeakyReLU(0.1), nn.MaxPool2d(2, 2), nn.Conv2d(cout, 64, 1), nn.LeakyReLU(0.1)).cuda()
+    plan = engine.Plan.from_modules(list(mods), cin, False)
+    H = 8 if W != 28 else 28
+    x = torch.randn(3, cin, H, W, device="cuda")
+    L = plan.layers[0]
+    L.Hout, L.Wout = H, W
+    assert engine.Plan._pool_fusable(L)
+    with torch.no_grad():
+        y_fused = engine.run_plan(plan, x, False)
+        engine.FUSE_POOL = False
+        try:
+            y_sep = engine.run_plan(plan, x, False)
+        finally:
+            engine.FUSE_POOL = True
+    assert torch.equal(y_fused, y_sep)
+
+    def train_pass():
+        for m in mods.parameters():
+            m.grad = None
+        xx = x.clone().requires_grad_(True)
+        y = engine.run_plan(plan, xx, True)
+        y.backward(torch.ones_like(y) / y.numel())
+        return y.detach().clone(), xx.grad.clone(), [m.grad.clone() for m in mods.parameters()]
+
+    ya, gxa, ga = train_pass()
+    engine.FUSE_POOL = False
+    try:
+        yb, gxb, gb = train_pass()
+    finally:
+        engine.FUSE_POOL = True
+    assert torch.equal(ya, yb) and torch.equal(gxa, gxb)
+    for a, b in zip(ga, gb):
+        torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-7)      # weight gradients: fp32 atomics order only

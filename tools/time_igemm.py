@@ -27,7 +27,7 @@ for item in synth.YOLOV1_BACKBONE_CFG:
     only = os.environ.get("LAYERS")
     if only and str(idx) not in only.split(","):
         continue
-    pool = int(os.environ.get("POOL", "0")) and idx in (0, 3)
+    pool = int(os.environ.get("POOL", "0")) and idx in (0, 3, 12, 33)      # the layers in front of a MaxPool2d
     if idx == 0:
         x = Act(N, hin, hin, 4, 3, dev)
     else:

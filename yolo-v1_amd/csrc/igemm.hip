@@ -764,7 +764,7 @@ YOLO_API int yolo_igemm(const yolo_igemm_desc *d, const void *in, const void *w,
         if (d->pool2) return fail(YOLO_E_UNSUPPORTED, "yolo_igemm: tile_hint 14 has no pooled epilogue");
         return launch<256, 208, 32, 4, 2, 4, MFMA_16x16x32_STAGGER_U>(p, splits, s);
     }
-    if (force == 15) return igemm_pipe_launch(p, splits, s);     // the same tile, register-pipelined one-barrier loop (igemm_pipe.hip)
+    if (force >= 15 && force <= 18) return igemm_pipe_launch(p, force, splits, s);     // register-pipelined one-barrier loop (igemm_pipe.hip)
     if (force == 13) return launch<256, 128, 32, 4, 2, 4, MFMA_16x16x32_STAGGER>(p, splits, s);
     if (force == 10) return launch<64, 128, 32, 2, 2, 2>(p, splits, s);     // 28 KB of LDS: five workgroups per CU (thin-K 1x1 layers)
     if (!bk64) {

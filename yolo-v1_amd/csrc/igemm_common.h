@@ -84,7 +84,7 @@ __device__ __forceinline__ void wait_vmcnt()
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-// igemm_pipe.hip: the register-pipelined one-barrier kernel (tile_hint 15); `splits` as for the other configurations
-int igemm_pipe_launch(const IgemmParams &p, int splits, hipStream_t s);
+// igemm_pipe.hip: the register-pipelined one-barrier kernels (tile_hint 15 .. 18); `splits` as for the other configurations
+int igemm_pipe_launch(const IgemmParams &p, int hint, int splits, hipStream_t s);
 
 }  // namespace yolo

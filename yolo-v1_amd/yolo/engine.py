@@ -130,7 +130,7 @@ def _flush_caches(dev):
 
 # tile edge (co, px slots) of the configurations the tuner may combine
 _TILE = {1: (128, 128), 3: (128, 64), 4: (64, 128), 5: (128, 128), 10: (64, 128), 11: (256, 128), 12: (256, 256), 13: (256, 128), 14: (256, 208),
-         15: (256, 208)}
+         15: (256, 208), 16: (256, 224), 17: (128, 208), 18: (128, 224)}
 _TAIL_CANDIDATES = (5, 3, 4)
 # (workgroup slots of the chip, relative time of one tile) per configuration, for _default_plan: 8-wave configurations run
 # one workgroup per CU, the 4-wave ones two; times are relative to a 256x256 tile and follow the measured in-tile rates
@@ -152,19 +152,35 @@ def _splitk_scratch(n: int, zero: bool) -> torch.Tensor:
     return v
 
 
+def _pipe_ok(d: IgemmDesc) -> bool:
+    """the register-pipelined kernels (tile_hint 15 .. 18) take the problem: an even number >= 4 of 32-deep K steps, no
+    BatchNorm statistics"""
+    nk = d.KH * d.KW * d.tap_len // 32
+    return d.tap_len % 32 == 0 and nk % 2 == 0 and nk >= 4 and not d.bn_stats and not d.w_blocked
+
+
+def _pipe_pool_ok(d: IgemmDesc) -> bool:
+    """... and their pooled epilogue (224-pixel tiles of whole row pairs) the output geometry"""
+    return _pipe_ok(d) and d.Wo in (112, 56, 28) and d.Ho % 2 == 0 and (d.Ho * d.Wo) % 112 == 0 and d.Cout % 8 == 0
+
+
 def _default_plan(d: IgemmDesc):
     """launch plan of a problem without a measured entry: the configuration with the smallest predicted time =
     rounds over the chip's workgroup slots x relative tile time (deterministic, no timing)."""
     M = d.N * d.Ho * d.Wo
-    if M < 2048 or d.pool2:
+    if d.pool2:
+        # the library's own pooled epilogue tiles 8 x 16 pixel patches; other maps go through the 224-pixel pipelined tiles
+        if d.Ho % 8 == 0 and d.Wo % 16 == 0 and not (_pipe_pool_ok(d) and d.Cout >= 192):
+            return (0, 0)
+        return ("tile", 16 if d.Cout > 128 else 18, 1, 0)
+    if M < 2048:
         return (0, 0)
     best, best_t = (0, 0), None
     for hint, (slots, cost) in _TILE_COST.items():
         tco, tpx = _TILE[hint]
         forms = [((hint, 1), tpx)]
         if hint == 14:
-            nk = d.KH * d.KW * d.tap_len // 32
-            h = 15 if (nk % 2 == 0 and nk >= 4 and not d.bn_stats) else 14     # the pipelined loop where it applies
+            h = 15 if _pipe_ok(d) else 14     # the pipelined loop where it applies
             forms = [(("tile", h, 1, 196), 196)] if M % 196 == 0 else [(("tile", h, 1, 208), 208)]
         for plan, px in forms:
             tiles = ((d.Cout + tco - 1) // tco) * ((M + px - 1) // px)
@@ -179,8 +195,8 @@ def _run_plan_igemm(L_, d: IgemmDesc, plan, inp, w, bias, aux, out, st, what):
     if d.bn_stats and (plan[0] in ("splitk", "slabs") or (isinstance(plan[0], int) and len(plan) == 4)):
         # a launch that also accumulates BatchNorm statistics must be one plain launch: keep the plan's main configuration
         plan = (plan[1], 1) if plan[0] in ("splitk", "slabs") else (plan[0], plan[1])
-    if d.bn_stats and plan[0] == "tile" and plan[1] == 15:
-        plan = ("tile", 14) + tuple(plan[2:])          # the pipelined kernel has no statistics epilogue: same tile, staggered loop
+    if d.bn_stats and plan[0] == "tile" and plan[1] in (15, 16, 17, 18):
+        plan = ("tile", 14, plan[2], min(plan[3], 208)) + tuple(plan[4:])   # the pipelined kernels have no statistics epilogue: staggered loop
     d.tile_px, d.px_begin, d.px_end, d.skew_phases, d.skew_step = 0, 0, 0, 0, 0
     if plan[0] in ("splitk", "slabs"):
         # few-pixel deep-K layer: S workgroups per output tile into a dense fp32 scratch (atomics, or one slab per split),
@@ -256,6 +272,8 @@ def _tune(L_, d: IgemmDesc, inp, w, bias, aux, out, st, what):
             times[plan] = t
 
     cands = [c for c in _TUNE_CANDIDATES if not (d.pool2 and c in (3, 12))]
+    if d.pool2 and not (d.Ho % 8 == 0 and d.Wo % 16 == 0):
+        cands = []                # the 8 x 16-patch pooled epilogue does not tile this map: pipelined 224-pixel tiles only
     if d.KH == 1 and d.KW == 1 and d.tap_len <= 256 and not d.pool2:
         cands.append(10)      # thin-K 1x1 layers stream: 64x128x32, 28 KB of LDS, five workgroups per CU
     orders = (1, 2) if (d.Cout * d.KH * d.KW * d.tap_len * 2 > (4 << 20) and d.Cout >= 1024) else (1,)
@@ -267,7 +285,15 @@ def _tune(L_, d: IgemmDesc, inp, w, bias, aux, out, st, what):
     if not d.pool2:
         for o in orders:
             consider(("tile", 14, o, tile_px))
-            consider(("tile", 15, o, tile_px))      # the same tile, register-pipelined one-barrier loop
+            if _pipe_ok(d):
+                consider(("tile", 15, o, tile_px))      # the same tile, register-pipelined one-barrier loop
+                consider(("tile", 17, o, tile_px))      # 128 channels x 208, two workgroups per CU (short-K layers)
+                if (d.Ho * d.Wo) % 112 == 0:
+                    consider(("tile", 16, o, 0))        # 224-pixel tiles
+                    consider(("tile", 18, o, 0))
+    elif _pipe_pool_ok(d):
+        consider(("tile", 16, 1, 0))                    # MaxPool2d(2,2) fused into the pipelined kernels' epilogue
+        consider(("tile", 18, 1, 0))
     # tail plans: the two fastest large-tile configurations, cut where their tiles stop filling whole rounds of
     # 256 (one workgroup per CU) or 512 slots, remainder with a small tile
     if times and not d.pool2:
@@ -712,6 +738,18 @@ class Plan:
         d.tile_hint, d.tile_px = TILE_HINT, TILE_PX
         return d
 
+    @staticmethod
+    def _pool_fusable(L: Layer) -> bool:
+        """conv -> LeakyReLU -> MaxPool2d(2,2) as one launch: the library's 8 x 16-patch pooled epilogue (224^2 and 112^2
+        maps), or the pipelined kernels' 224-pixel tiles of whole row pairs (rows of 112, 56 or 28 pixels)"""
+        if L.Cout % 8:
+            return False
+        if L.Hout % 8 == 0 and L.Wout % 16 == 0:
+            return True
+        nk = L.K * L.K * L.Cin // 32
+        return (not L.first and L.Cin % 32 == 0 and nk % 2 == 0 and nk >= 4 and L.Wout in (112, 56, 28) and L.Hout % 2 == 0
+                and (L.Hout * L.Wout) % 112 == 0)
+
     # ------------------------------------------------------------------ forward
     @_hip.device_guard
     def forward(self, x: torch.Tensor, train: bool, drop_training: bool, u8_size=None):
@@ -755,7 +793,7 @@ class Plan:
                 # 8 x 16 pixel patches (the first two layers: 224^2 and 112^2); training keeps the un-pooled
                 # activation, which the backward pass needs
                 fuse = (not train and FUSE_POOL and li + 1 < len(self.layers) and self.layers[li + 1].kind == "pool"
-                        and L.Hout % 8 == 0 and L.Wout % 16 == 0 and L.Cout % 8 == 0)
+                        and self._pool_fusable(L))
                 if fuse:
                     nxt = ws["acts"][li + 1]
                 d = self._conv_desc(L, cur, nxt)
@@ -777,7 +815,7 @@ class Plan:
                     continue
                 # training: the same fused pool, with the un-pooled activation written too (pool2 = 2)
                 dual = (train and FUSE_POOL and not fuse and li + 1 < len(self.layers) and self.layers[li + 1].kind == "pool"
-                        and L.Hout % 8 == 0 and L.Wout % 16 == 0 and L.Cout % 8 == 0 and not L.first)
+                        and self._pool_fusable(L) and not L.first)
                 if dual:
                     full, pooled = nxt, ws["acts"][li + 1]
                     d = self._conv_desc(L, cur, pooled)
