@@ -216,8 +216,10 @@ typedef struct yolo_wgrad_desc {
                                         several workgroups are accumulated with atomics, the others stored) */
     int32_t accumulate;              /* 1: add into dw even when split == 1                       */
     int32_t variant;                 /* 0: choose; 1: 128x128 tile, 4 waves, 2 stages; 2: 256x128 tile, 8 waves, 3 stages;
-                                        3: 2 + staggered two-phase schedule; 4: 128x128 tile, 8 waves (tests / tuning;
-                                        all agree bit for bit)                                      */
+                                        3: 2 + staggered two-phase schedule; 4: 128x128 tile, 8 waves; 5: 256x256 tile, wave
+                                        tile 128x64, four 32-pixel stages, register-pipelined one-barrier loop
+                                        (wgrad_pipe.hip; Cin in {64, 128}: 256 / Cin taps per tile)  (tests / tuning;
+                                        all agree bit for bit with one pixel range per tile)        */
     /* Pixel geometry (geo_W == 0: "flat" indexing, p IS the slot).  Otherwise the reduction runs over the P = N*geo_H*geo_W
      * pixels p = (n*geo_H + oy)*geo_W + ox only, and pixel p lives in slot
      *     n*geo_img_slots + oy*geo_row_slots + ox*geo_px_slots + geo_slot0

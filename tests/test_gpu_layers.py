@@ -297,7 +297,7 @@ def test_stem_wgrad_direct_kernel():
                                   ptr(dw2), ptr(db2), ptr(part), part.numel(), stream()) != 0
 
 
-@pytest.mark.parametrize("Cin", [192, 64])
+@pytest.mark.parametrize("Cin", [192, 64, 128, 512])
 def test_wgrad_kernel_variants_agree_bit_for_bit(Cin):
     """yolo_wgrad: the 128x128 kernel, the 256x128 3-stage kernel and its staggered two-phase form reduce every output over
     the pixels in the same order (16-pixel MFMA sub-steps), so with one pixel range per tile they must agree bit for bit --
@@ -311,7 +311,7 @@ def test_wgrad_kernel_variants_agree_bit_for_bit(Cin):
     x.interior().copy_(torch.randn(N, H, W, Cin, device="cuda").to(torch.bfloat16))
     dy.interior().copy_((torch.randn(N, H, W, Cout, device="cuda") * 0.1).to(torch.bfloat16))
     outs = []
-    for variant in (1, 2, 3, 4):
+    for variant in (1, 2, 3, 4, 5):          # 5: 256 x 256 tile, register-pipelined loop (wgrad_pipe.hip)
         dw = torch.full((Cout, 3, 3, Cin), float("nan"), device="cuda")
         db = torch.zeros(Cout, device="cuda")
         wd = WgradDesc(dy.slots, dy.px_stride, x.px_stride, Cout, Cin, 3, 3, 1, x.row_stride, 1, 0, variant)
@@ -322,6 +322,14 @@ def test_wgrad_kernel_variants_agree_bit_for_bit(Cin):
     torch.testing.assert_close(outs[0][0], ref, rtol=2e-3, atol=2e-3)
     for dw, db in outs[1:]:
         assert torch.equal(dw, outs[0][0]) and torch.equal(db, outs[0][1])
+    # the pipelined kernel in pixel-geometry mode (interior pixels only) and with the library's two-segment schedule (atomics)
+    for split in (1, 0):
+        dw = torch.zeros((Cout, 3, 3, Cin), device="cuda")
+        db = torch.zeros(Cout, device="cuda")
+        wd = WgradDesc(N * H * W, dy.px_stride, x.px_stride, Cout, Cin, 3, 3, 1, x.row_stride, split, 0, 5, W, H, dy.Hp * dy.Wp, dy.Wp, 1, dy.halo * dy.Wp + dy.halo)
+        check(lib().yolo_wgrad(ctypes.byref(wd), x.p, dy.p, ptr(dw), ptr(db), stream()))
+        torch.testing.assert_close(dw, outs[0][0], rtol=1e-4, atol=1e-4)
+        torch.testing.assert_close(db, outs[0][1], rtol=1e-4, atol=1e-4)
 
 
 def test_stride2_data_gradient_by_parity_classes():

@@ -9,7 +9,7 @@ from yolo._hip import lib, check, ptr, stream, WgradDesc
 from yolo.engine import Act
 
 N = 64
-VARIANT = int(os.environ.get("VARIANT", "0"))
+VARIANTS = [int(v) for v in os.environ.get("VARIANT", "0").split(",")]     # several: interleaved A/B in one process
 INDEX = int(os.environ.get("INDEX", "0"))
 SPLITS = [int(v) for v in os.environ.get("SPLITS", "").split(",") if v]
 ONLY = [int(v) for v in os.environ.get("LAYERS", "").split(",") if v]
@@ -33,9 +33,11 @@ for item in synth.YOLOV1_BACKBONE_CFG:
     db = torch.zeros((co,), dtype=torch.float32, device=dev)
     tiles = ((co + 127) // 128) * ((ci + 127) // 128) * k * k
     for split in (SPLITS or sorted(set([max(1, min(dy.slots // 256, (1024 + tiles - 1) // tiles)), max(1, (256 + tiles - 1) // tiles), max(1, (512 + tiles - 1) // tiles)]))):
-        wds = {"flat": WgradDesc(dy.slots, dy.px_stride, x.px_stride, co, ci, k, k, p, x.row_stride, split, 0, VARIANT),
-               "geo": WgradDesc(N * h * h, dy.px_stride, x.px_stride, co, ci, k, k, p, x.row_stride, split, 0, VARIANT, h, h, dy.Hp * dy.Wp, dy.Wp * s, s, dy.Wp + 1)}
-        modes = ["flat", "geo"] if INDEX == 2 else (["geo"] if INDEX else ["flat"])
+        wds, modes = {}, []
+        for V in VARIANTS:
+            wds[f"v{V} flat"] = WgradDesc(dy.slots, dy.px_stride, x.px_stride, co, ci, k, k, p, x.row_stride, split, 0, V)
+            wds[f"v{V} geo"] = WgradDesc(N * h * h, dy.px_stride, x.px_stride, co, ci, k, k, p, x.row_stride, split, 0, V, h, h, dy.Hp * dy.Wp, dy.Wp * s, s, dy.Wp + 1)
+            modes += [f"v{V} flat", f"v{V} geo"] if INDEX == 2 else ([f"v{V} geo"] if INDEX else [f"v{V} flat"])
         res = {m: [] for m in modes}
         for rep in range(3):                      # interleaved A/B inside one process
             for m in modes:

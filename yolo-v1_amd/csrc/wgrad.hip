@@ -17,87 +17,11 @@
 // Split over pixel ranges (blockIdx.y) with fp32 atomics into the packed gradient.
 // Replaces the weight-gradient half of aten convolution_backward / addmm backward for
 // src/yolo/models.py:47-84,239-245,313-332.
-#include <algorithm>
-#include <type_traits>
-
-#include "common.h"
+#include "wgrad_common.h"
 
 namespace yolo {
 
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
-typedef __attribute__((ext_vector_type(4))) short s16x4;
-typedef __attribute__((ext_vector_type(16))) float f32x16;
-
 __device__ uint4 g_zero_line[16];  // 256 B of zeros: source for out-of-range rows
-
-struct WgradParams {
-    const bf16_t *x;
-    const bf16_t *dy;
-    float *dw;
-    float *db;              // optional: bias gradient, accumulated by the (tap 0, ci-tile 0) workgroups
-    long P;                 // pixels to reduce over
-    // pixel p -> slot in the dy / x buffers.  gW == 0: p is the slot ("flat" indexing).  Else p = (n*gH + oy)*gW + ox and
-    // slot = n*g_img + oy*g_row + ox*g_px + g_off (interior pixels of a zero-haloed buffer, optionally every 2nd one);
-    // mW, mH = ceil(2^32 / gW), ceil(2^32 / gH) turn the small divisions into v_mul_hi_u32
-    int gW, gH, g_img, g_row, g_px, g_off;
-    unsigned mW, mH;
-    long p_per_split;
-    int dy_px_stride, x_px_stride;
-    int Cout, Cin, Cout_ld, Cin_ld;  // logical sizes and loadable (multiple-of-8) widths
-    int KH, KW, pad;
-    long x_row_stride;
-    int n_co_tiles, n_ci_tiles, ntaps;
-    int pair_taps;          // Cin == 64 (128 x 128 kernel): a ci-tile holds TWO taps (columns 0..63 / 64..127 are adjacent in
-                            // dw[co][tap][ci]), so half the tile is not wasted on padding; tile index = pair index then
-    int atomic;             // uniform split: accumulate with atomics.  Two-segment schedule: bit 0 = main segment, bit 1 = tail
-    // two-segment schedule (seg = 1, 1-D grid): the first main_tiles tiles are split into main_split pixel ranges and fill
-    // whole rounds of the chip's 512 workgroup slots; the remaining tail_tiles (< 512 / main_split) tiles are split finer
-    // (tail_split ranges) so that they fill one more, shorter round instead of leaving most CUs idle for a full-length one
-    int seg, slots;         // slots: resident workgroups on the chip (512 for the 128x128 kernel, 256 for the 256x128 ones)
-    int main_tiles, main_split, tail_tiles, tail_split;
-    long per_main, per_tail;
-};
-
-constexpr int WG_SLOTS = 512;   // 256 CUs x 2 resident workgroups (64 KB of LDS each)
-
-// workgroup -> (logical tile id, first pixel, pixels).  Hardware hands consecutive workgroup ids to the 8 XCDs round-robin;
-// within every group of 512 ids an XCD gets 64 CONSECUTIVE logical workgroups: same pixel range, neighbouring tiles
-// (co fastest), so the dy / x rows they stream are shared through that XCD's L2.
-__device__ __forceinline__ void wgrad_map(const WgradParams &p, int nwg, int &bid, long &pbeg, long &pend, bool &atomic)
-{
-    atomic = p.atomic & 1;
-    if (p.seg) {
-        const int id = blockIdx.x, per_xcd = p.slots >> 3;
-        const int L = id / p.slots * p.slots + (id & 7) * per_xcd + ((id % p.slots) >> 3);
-        const int nmain = p.main_tiles * p.main_split;
-        int range;
-        long per;
-        if (L < nmain) {
-            const int tpr = p.slots / p.main_split;           // tiles per round
-            const int round = L / p.slots, within = L % p.slots;
-            range = within / tpr;
-            bid = round * tpr + within % tpr;
-            per = p.per_main;
-        } else {
-            const int t = L - nmain, tt = max(p.tail_tiles, 1);
-            range = p.tail_tiles > 0 ? t / tt : p.tail_split;   // no tail: past every range -> empty
-            bid = p.main_tiles + t % tt;
-            per = p.per_tail;
-            atomic = (p.atomic >> 1) & 1;
-        }
-        pbeg = (long)range * per;
-        pend = min(p.P, pbeg + per);
-        if (bid >= nwg) pend = pbeg;   // ids past the last logical workgroup (grid rounded up to the XCD map)
-    } else {
-        const int q = nwg >> 3, r = nwg & 7, xcd = blockIdx.x & 7, k = blockIdx.x >> 3;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
-        pbeg = (long)blockIdx.y * p.p_per_split;
-        pend = min(p.P, pbeg + p.p_per_split);
-    }
-}
-
-#define GLDS16(gptr, lptr) \
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gptr), (__attribute__((address_space(3))) void *)(lptr), 16, 0, 0)
 
 // the same instruction from inline asm, invisible to the compiler's LDS alias / waitcnt tracking (wgrad256_kernel);
 // lds = wave-uniform LDS byte address of the wave's 1-KB destination
@@ -1168,13 +1092,21 @@ YOLO_API int yolo_wgrad(const yolo_wgrad_desc *d, const void *x, const void *dy,
         p.n_ci_tiles = (d->Cin + WG_T - 1) / WG_T;
         p.ntaps = d->KH * d->KW;
         // Cin == 64 with several taps (the 64 -> 192 3x3 layer): two taps per 128-column tile instead of half-empty tiles
-        p.pair_taps = ((d->variant <= 1 || d->variant == 4) && d->Cin == 64 && p.ntaps > 1 && d->x_px_stride >= 64) ? 1 : 0;
+        p.pair_taps = ((d->variant <= 1 || d->variant == 4) && d->variant != 5 && d->Cin == 64 && p.ntaps > 1 && d->x_px_stride >= 64) ? 1 : 0;
         const long steps_total = (d->P + WG_BP - 1) / WG_BP;
         // kernel variant: 256-wide co tiles (8 waves, 3 stages) only on request (d->variant == 2): measured no faster
         // than two co-resident 128 x 128 workgroups on any layer of the model
         const bool big = d->variant == 2 || d->variant == 3;   // 3: + staggered two-phase schedule
+        const bool pipe = d->variant == 5;                      // 256 x 256 tile, register-pipelined loop (wgrad_pipe.hip)
         p.n_co_tiles = big ? (d->Cout + W2_TCO - 1) / W2_TCO : (d->Cout + WG_T - 1) / WG_T;
-        const int tiles = p.n_co_tiles * p.n_ci_tiles * (p.pair_taps ? (p.ntaps + 1) / 2 : p.ntaps);
+        int tiles = p.n_co_tiles * p.n_ci_tiles * (p.pair_taps ? (p.ntaps + 1) / 2 : p.ntaps);
+        p.tile_taps = 1;
+        if (pipe) {
+            p.tile_taps = (d->Cin < 256 && 256 % d->Cin == 0 && p.ntaps > 1 && d->x_px_stride >= d->Cin) ? 256 / d->Cin : 1;
+            p.n_co_tiles = (d->Cout + 255) / 256;
+            p.n_ci_tiles = p.tile_taps > 1 ? 1 : (d->Cin + 255) / 256;
+            tiles = p.n_co_tiles * p.n_ci_tiles * ((p.ntaps + p.tile_taps - 1) / p.tile_taps);
+        }
         dim3 grid;
         if (d->split > 0) {
             // uniform split, 2-D grid (tiles x ranges)
@@ -1187,7 +1119,7 @@ YOLO_API int yolo_wgrad(const yolo_wgrad_desc *d, const void *x, const void *dy,
         } else {
             // split == 0: two-segment schedule (see WgradParams), dw is accumulated.  Cost model in K steps: a round of
             // workgroups costs its K steps + ~30 steps' worth of prologue and atomic epilogue (fitted on the 3x3 layers).
-            const int slots = big ? WG_SLOTS / 2 : WG_SLOTS;
+            const int slots = (big || pipe) ? WG_SLOTS / 2 : WG_SLOTS;
             const double E = 30.0;
             double best = 1e30;
             int bs = 1, bt = 1;
@@ -1215,7 +1147,9 @@ YOLO_API int yolo_wgrad(const yolo_wgrad_desc *d, const void *x, const void *dy,
             const long nblk = (long)p.main_tiles * bs + (long)p.tail_tiles * p.tail_split;
             grid = dim3((unsigned)((nblk + slots - 1) / slots * slots));   // whole groups of `slots` ids for the XCD map
         }
-        if (big) {
+        if (pipe) {
+            if (int rc = wgrad_pipe_launch(p, grid, s)) return rc;
+        } else if (big) {
             static bool lds_ok = false;
             if (!lds_ok) {
                 hipError_t e = hipFuncSetAttribute((const void *)wgrad256_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * W2_STAGE);

@@ -44,6 +44,7 @@ IGEMM_LAUNCHES = 0  # yolo_igemm launches so far (bench.py: launches per step of
 STEM_KERNEL = True  # 7x7/s2 stem through yolo_conv_stem7_fwd (False: the generic row-segment implicit GEMM; tests compare)
 STEM_POOL_BWD_FUSED = True  # backward of the pool + LeakyReLU behind the stem inside yolo_wgrad_stem7_pooled (False: separate pass)
 STRIDE2_CLASSES = True  # data gradient of a stride-2 3x3 conv as four parity-class convs over the non-zero gradient slots
+WGRAD_PIPE = True  # weight gradient of the big deep 3x3 layers through wgrad_pipe.hip (yolo_wgrad_desc.variant = 5)
 FUSE_POOL = True   # inference: fold MaxPool2d(2,2) into the preceding conv's epilogue where the geometry allows
 
 
@@ -923,10 +924,13 @@ class Plan:
     @staticmethod
     def _wgrad_desc(L: Layer, g: Act, xin: Act, N: int) -> WgradDesc:
         """yolo_wgrad problem of conv layer L over N images of the gradient buffer g / the input buffer xin"""
-        if L.Hout >= 2 and L.Wout >= 2 and (L.stride > 1 or g.Hp * g.Wp >= 1.12 * L.Hout * L.Wout):
-            return WgradDesc(N * L.Hout * L.Wout, g.px_stride, xin.px_stride, L.Cout, L.Cin, L.K, L.K, L.pad, xin.row_stride, 0, 0, 0,
+        # kernel variant: the 256 x 256 pipelined kernel (5) on the big deep layers, where the in-process A/B measured it 8-9 %
+        # faster (56x56 256 -> 512, 28x28 512 -> 1024: tools/time_wgrad.py); the 128 x 128 kernel (0) everywhere else
+        variant = 5 if (WGRAD_PIPE and L.K == 3 and L.stride == 1 and L.Cout >= 512 and L.Cin >= 256 and N * L.Hout * L.Wout >= 40000) else 0
+        if variant == 5 or (L.Hout >= 2 and L.Wout >= 2 and (L.stride > 1 or g.Hp * g.Wp >= 1.12 * L.Hout * L.Wout)):
+            return WgradDesc(N * L.Hout * L.Wout, g.px_stride, xin.px_stride, L.Cout, L.Cin, L.K, L.K, L.pad, xin.row_stride, 0, 0, variant,
                              L.Wout, L.Hout, g.Hp * g.Wp, g.Wp * L.stride, L.stride, g.halo * g.Wp + g.halo)
-        return WgradDesc(N * g.Hp * g.Wp, g.px_stride, xin.px_stride, L.Cout, L.Cin, L.K, L.K, L.pad, xin.row_stride, 0, 0)
+        return WgradDesc(N * g.Hp * g.Wp, g.px_stride, xin.px_stride, L.Cout, L.Cin, L.K, L.K, L.pad, xin.row_stride, 0, 0, variant)
 
     def backward(self, saved, gout: torch.Tensor, need_gx: bool):
         """gout: gradient of the plan output (same shape as forward's out).  Returns (gx or None, [param grads])."""
