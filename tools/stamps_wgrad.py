@@ -1,0 +1,49 @@
+#!/usr/bin/env python3
+"""Where one 32-pixel stage of wgrad_pipe_kernel (yolo_wgrad variant 5) spends its cycles -- diagnostic build with s_memtime stamps.
+
+    make -C yolo-v1_amd/csrc diag && YOLO_HIP_LIB=yolo-v1_amd/yolo/libyolo_hip_diag.so python tools/stamps_wgrad.py [LAYER] [STAGE]
+
+segments: barrier wait | sub-step 0: six MFMAs + 12 transposing reads + address arithmetic | DMA pair 0 | MFMA 7 + DMA pair 1 |
+          MFMA 8 | sub-step 1: eight MFMAs + 12 reads"""
+import ctypes, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "yolo-v1_amd")); sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+import torch
+import synth
+from yolo._hip import lib, check, ptr, stream, WgradDesc
+from yolo.engine import Act
+
+layer = int(sys.argv[1]) if len(sys.argv) > 1 else 12
+stage = int(sys.argv[2]) if len(sys.argv) > 2 else 100
+N, dev, h = 64, torch.device("cuda"), 448
+for item in synth.YOLOV1_BACKBONE_CFG:
+    if item == "M":
+        h //= 2
+        continue
+    idx, (co, ci, k, s, p) = item
+    hin = h
+    h = (h + 2 * p - k) // s + 1
+    if idx != layer:
+        continue
+    x = Act(N, h, h, ci, 1, dev); dy = Act(N, h, h, co, 1, dev)
+    x.t.normal_(); dy.t.normal_()
+    dwp = torch.zeros((co, k, k, ci), dtype=torch.float32, device=dev)
+    wd = WgradDesc(N * h * h, dy.px_stride, x.px_stride, co, ci, k, k, p, x.row_stride, 0, 0, 5, h, h, dy.Hp * dy.Wp, dy.Wp, 1, dy.Wp + 1)
+    buf = torch.zeros(512 * 64, dtype=torch.int64, device=dev)
+    for _ in range(10):
+        check(lib().yolo_wgrad(ctypes.byref(wd), x.p, dy.p, ptr(dwp), None, stream()))
+    check(lib().yolo_debug_stamps(ptr(buf), stage))
+    for _ in range(3):
+        check(lib().yolo_wgrad(ctypes.byref(wd), x.p, dy.p, ptr(dwp), None, stream()))
+    torch.cuda.synchronize()
+    check(lib().yolo_debug_stamps(None, 0))
+    st = buf.cpu().view(512, 8, 8).double()
+    ok = st[:, 0, 6] > 0
+    seg = (st[:, :, 1:7] - st[:, :, 0:6])[ok].reshape(-1, 6)
+    print(f"layer {layer} stage {stage}: {int(ok.sum())} workgroups stamped; median cycles per wave")
+    print("  barrier %5.0f | 4 MFMA + 12 reads + addresses %5.0f | DMA + 2 MFMA %5.0f | DMA + 2 MFMA %5.0f | 4 MFMA + 12 reads %5.0f | 2 x (DMA + 2 MFMA) %5.0f | total %6.0f"
+          % (*seg.median(0).values.tolist(), (st[:, :, 6] - st[:, :, 0])[ok].median().item()))
+    m = st[int(ok.nonzero()[0])]
+    print("  first stamped workgroup, stamps of wave w relative to the earliest:")
+    for wv in range(8):
+        print("    w%d " % wv + " ".join("%6.0f" % (v - m[:, :7].min().item()) for v in m[wv, :7].tolist()))

@@ -685,6 +685,14 @@ using namespace yolo;
 static long *g_dbg = nullptr;
 static int g_dbg_it = 0;
 
+namespace yolo {
+void debug_stamp_target(long **buf, int *it)
+{
+    *buf = g_dbg;
+    *it = g_dbg_it;
+}
+}  // namespace yolo
+
 YOLO_API int yolo_debug_stamps(void *buf, int k_iter)
 {
     g_dbg = (long *)buf;

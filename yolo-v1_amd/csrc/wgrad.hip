@@ -1102,6 +1102,14 @@ YOLO_API int yolo_wgrad(const yolo_wgrad_desc *d, const void *x, const void *dy,
         int tiles = p.n_co_tiles * p.n_ci_tiles * (p.pair_taps ? (p.ntaps + 1) / 2 : p.ntaps);
         p.tile_taps = 1;
         if (pipe) {
+            // 32-bit byte offsets from the operand bases, 24-bit slot arithmetic; a pixel range that ends inside a 32-pixel stage
+            // reads halo slot 0 for the missing rows, which a Linear layer's operands (no halo) do not have
+            const long max_slot = d->geo_W > 0 ? (d->P / ((long)d->geo_W * d->geo_H)) * (long)d->geo_img_slots + d->geo_slot0 : d->P;
+            if (max_slot >= (1L << 24) || max_slot * (long)std::max(d->dy_px_stride, d->x_px_stride) * 2 + 4 * (long)d->pad * (d->x_row_stride + d->x_px_stride) >= (1L << 32)
+                || d->dy_px_stride >= (1 << 23) || d->x_px_stride >= (1 << 23))
+                return fail(YOLO_E_UNSUPPORTED, "yolo_wgrad: variant 5 addresses operands below 4 GB with fewer than 2^24 pixel slots");
+            if (d->geo_W == 0 && d->pad == 0 && d->KH * d->KW == 1 && (d->P % 32))
+                return fail(YOLO_E_UNSUPPORTED, "yolo_wgrad: variant 5 needs zero-haloed operands or P %% 32 == 0");
             p.tile_taps = (d->Cin < 256 && 256 % d->Cin == 0 && p.ntaps > 1 && d->x_px_stride >= d->Cin) ? 256 / d->Cin : 1;
             p.n_co_tiles = (d->Cout + 255) / 256;
             p.n_ci_tiles = p.tile_taps > 1 ? 1 : (d->Cin + 255) / 256;

@@ -32,6 +32,8 @@ struct WgradParams {
     int n_co_tiles, n_ci_tiles, ntaps;
     int pair_taps;          // Cin == 64 (128 x 128 kernel): a ci-tile holds TWO taps (columns 0..63 / 64..127 are adjacent in
                             // dw[co][tap][ci]), so half the tile is not wasted on padding; tile index = pair index then
+    long *dbg;              // diagnostic builds (-DIGEMM_STAMPS): s_memtime stamps of stage dbg_it (yolo_debug_stamps)
+    int dbg_it;
     int tile_taps;          // wgrad_pipe (256-column tiles): taps per ci-tile = 256 / Cin when Cin < 256 divides 256 (columns of adjacent
                             // taps are adjacent in dw[co][tap][ci]), else 1
     int atomic;             // uniform split: accumulate with atomics.  Two-segment schedule: bit 0 = main segment, bit 1 = tail
@@ -86,5 +88,7 @@ __device__ __forceinline__ void wgrad_map(const WgradParams &p, int nwg, int &bi
 
 // wgrad_pipe.hip: 256 x 256 tile, wave tile 128 x 64, register-pipelined one-barrier loop (yolo_wgrad_desc.variant = 5)
 int wgrad_pipe_launch(const WgradParams &p, dim3 grid, hipStream_t s);
+// igemm.hip: the debug buffer of yolo_debug_stamps (diagnostic builds)
+void debug_stamp_target(long **buf, int *it);
 
 }  // namespace yolo

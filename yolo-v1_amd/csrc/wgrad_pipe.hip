@@ -31,10 +31,8 @@ typedef __attribute__((address_space(3))) s16x4 *lds_s16x4_p;
 // transposing reads as possible aliases of every outstanding LDS-DMA and drains vmcnt(0) in front of them -- the whole
 // prefetch ring would collapse to depth 0.  lds = wave-uniform LDS byte address of the wave's 1-KB destination; the waits
 // are counted by hand below.
-#define WP_DMA16(gptr, lds) \
-    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gptr), "s"(lds) : "memory", "m0")
-
-__device__ uint4 g_zero_line_p[32];  // 512 B of zeros: source for out-of-range rows / taps
+#define WP_DMA16(voff, base, lds) \
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(base), "s"(lds) : "memory", "m0")
 
 template <int N>
 __device__ __forceinline__ void wp_wait_vmcnt()
@@ -46,6 +44,8 @@ struct WPFrag {
     bf16x8 a[4], b[2];
 };
 
+// GEO: pixel-geometry indexing (compile-time: a run-time branch inside the stage would split its basic block and undo the interleave)
+template <bool GEO>
 __global__ void __launch_bounds__(wp::NTHR, 2) wgrad_pipe_kernel(const WgradParams p)
 {
     using namespace wp;
@@ -73,8 +73,17 @@ __global__ void __launch_bounds__(wp::NTHR, 2) wgrad_pipe_kernel(const WgradPara
     // ---- LDS-DMA pieces.  A wave-instruction covers 2 pixel rows x 512 B; slot (row, c') holds data chunk
     // c = c' ^ ((row & 3) << 2): the transposing reads of a 32-lane half then touch 16 distinct 16-B slots of the 256-B bank row.
     // Piece i of this wave = rows 16 i + 2 wave + {0, 1}; the same rows for the dy and the x tile.
+    // Addresses are scalar base + per-lane 32-bit BYTE offset (saddr form): in-kernel stamps showed the 64-bit per-row address
+    // arithmetic of wgrad.hip's scheme (two 64-bit multiplies per row and operand, quarter-rate v_mul_*_u32) taking 700-1200 of the
+    // ~2000 cycles of a stage.  Slots and strides are < 2^24, so the products are 24-bit multiplies.  The x base is moved back by
+    // G = |most negative tap offset| so that every offset is >= 0; rows past the pixel range and taps past the last one read a
+    // halo slot / a valid tap instead of a zero line (dy is exactly zero on its halo, so such rows add nothing; columns of
+    // missing taps are never stored).
     int row_of[2];
-    long a_coff[2], b_coff[2];          // element offsets added to slot * px_stride; b: tap offset + channel; < 0: zeros
+    unsigned a_cb[2], b_cb[2];          // constant byte offsets: channel chunk (+ tap offset + G for x)
+    const long G = (long)p.pad * p.x_row_stride + (long)p.pad * p.x_px_stride;
+    const char *const dyb = reinterpret_cast<const char *>(p.dy);
+    const char *const xb = reinterpret_cast<const char *>(p.x) - 2 * G;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int pos = (i * NW + wave) * 64 + lane;
@@ -83,19 +92,20 @@ __global__ void __launch_bounds__(wp::NTHR, 2) wgrad_pipe_kernel(const WgradPara
         row_of[i] = row;
         int ca = co0 / 8 + c;
         if (ca >= p.Cout_ld / 8) ca = p.Cout_ld / 8 - 1;
-        a_coff[i] = (long)ca * 8;
+        a_cb[i] = (unsigned)ca * 16u;
         const int tt = p.tile_taps > 1 ? c / cpt : 0;                 // tap of this chunk inside the tile
         int cb = p.tile_taps > 1 ? c - tt * cpt : ci0 / 8 + c;
         if (cb >= p.Cin_ld / 8) cb = p.Cin_ld / 8 - 1;
-        const int tap = tap0 + tt;
+        int tap = tap0 + tt;
+        if (tap >= p.ntaps) tap = p.ntaps - 1;                        // columns of a missing tap are never stored
         const int ky = tap / p.KW, kx = tap - ky * p.KW;
-        b_coff[i] = tap < p.ntaps ? (long)(ky - p.pad) * p.x_row_stride + (long)(kx - p.pad) * p.x_px_stride + cb * 8 : -(1L << 60);
+        b_cb[i] = (unsigned)(2 * ((long)(ky - p.pad) * p.x_row_stride + (long)(kx - p.pad) * p.x_px_stride + G) + cb * 16);
     }
-    const bf16_t *zline = reinterpret_cast<const bf16_t *>(g_zero_line_p) + (lane & 31) * 8;
+    const unsigned dy_sb = (unsigned)p.dy_px_stride * 2u, x_sb = (unsigned)p.x_px_stride * 2u;   // bytes per pixel slot
 
     // (n0, oy0, ox0) = pixel coordinates of the first row of the NEXT stage to issue (geometry mode), as wgrad.hip
     int n0 = 0, oy0 = 0, ox0 = 0;
-    if (p.gW) {
+    if constexpr (GEO) {
         const long row = pbeg / p.gW;
         ox0 = (int)(pbeg - row * p.gW);
         n0 = (int)(row / p.gH);
@@ -103,47 +113,49 @@ __global__ void __launch_bounds__(wp::NTHR, 2) wgrad_pipe_kernel(const WgradPara
     }
     const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char *)smem;
     long pb_next = pbeg;               // first pixel of the next stage to issue
-    // source addresses of the wave's two piece pairs (dy + x rows 16 i + 2 wave + {0, 1}) of the next stage -- plain VALU work
-    // that the scheduler spreads over the MFMA gaps -- and the stage coordinates advanced by one stage
-    auto stage_addr = [&](const bf16_t *(&sa)[2], const bf16_t *(&sx)[2]) {
+    // byte offsets of the wave's two piece pairs (dy + x rows 16 i + 2 wave + {0, 1}) of the next stage -- cheap VALU work that the
+    // scheduler spreads over the MFMA gaps -- and the stage coordinates advanced by one stage
+    auto stage_addr = [&](unsigned (&va)[2], unsigned (&vx)[2]) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const long pr = pb_next + row_of[i];
-            long slot;
-            if (p.gW) {
+            unsigned slot;
+            if constexpr (GEO) {
                 const unsigned a = (unsigned)(ox0 + row_of[i]);
                 const unsigned qx = __umulhi(a, p.mW);
                 const unsigned b = (unsigned)oy0 + qx;
                 const unsigned qy = __umulhi(b, p.mH);
-                slot = (long)(n0 + (int)qy) * p.g_img + (int)(b - qy * p.gH) * p.g_row + (int)(a - qx * p.gW) * p.g_px + p.g_off;
+                slot = __umul24((unsigned)n0 + qy, (unsigned)p.g_img) + __umul24(b - __umul24(qy, (unsigned)p.gH), (unsigned)p.g_row)
+                       + __umul24(a - __umul24(qx, (unsigned)p.gW), (unsigned)p.g_px) + (unsigned)p.g_off;
             } else {
-                slot = pr;
+                slot = (unsigned)pr;
             }
-            const bool ok = pr < pend;
-            sa[i] = ok ? p.dy + slot * p.dy_px_stride + a_coff[i] : zline;
-            sx[i] = (ok && b_coff[i] > -(1L << 59)) ? p.x + slot * p.x_px_stride + b_coff[i] : zline;
+            slot = pr < pend ? slot : 0u;      // slot 0 is a halo slot of the first image: dy is zero there
+            va[i] = __umul24(slot, dy_sb) + a_cb[i];
+            vx[i] = __umul24(slot, x_sb) + b_cb[i];
         }
         pb_next += BP;
-        if (p.gW) {
+        if constexpr (GEO) {
             const unsigned a = (unsigned)(ox0 + BP);
             const unsigned qx = __umulhi(a, p.mW);
             const unsigned b = (unsigned)oy0 + qx;
             const unsigned qy = __umulhi(b, p.mH);
-            ox0 = (int)(a - qx * p.gW);
-            oy0 = (int)(b - qy * p.gH);
+            ox0 = (int)(a - __umul24(qx, (unsigned)p.gW));
+            oy0 = (int)(b - __umul24(qy, (unsigned)p.gH));
             n0 += (int)qy;
         }
     };
-    auto stage_issue = [&](int buf, int i, const bf16_t *sa, const bf16_t *sx) {
-        const unsigned sb = lds0 + buf * STAGE_BYTES + (i * NW + wave) * 1024;
-        WP_DMA16(sa, sb);
-        WP_DMA16(sx, sb + TILE_BYTES);
+    auto issue_dy = [&](int buf, int i, unsigned va) { WP_DMA16(va, dyb, lds0 + buf * STAGE_BYTES + (i * NW + wave) * 1024); };
+    auto issue_x = [&](int buf, int i, unsigned vx) { WP_DMA16(vx, xb, lds0 + buf * STAGE_BYTES + TILE_BYTES + (i * NW + wave) * 1024); };
+    auto stage_issue = [&](int buf, int i, unsigned va, unsigned vx) {
+        issue_dy(buf, i, va);
+        issue_x(buf, i, vx);
     };
     auto stage = [&](int buf) {
-        const bf16_t *sa[2], *sx[2];
-        stage_addr(sa, sx);
-        stage_issue(buf, 0, sa[0], sx[0]);
-        stage_issue(buf, 1, sa[1], sx[1]);
+        unsigned va[2], vx[2];
+        stage_addr(va, vx);
+        stage_issue(buf, 0, va[0], vx[0]);
+        stage_issue(buf, 1, va[1], vx[1]);
     };
 
     // ---- transposing fragment reads (wgrad.hip): group g = lane >> 4 supplies rows (g >> 1) * 8 + q (+4 for the second read),
@@ -197,7 +209,7 @@ __global__ void __launch_bounds__(wp::NTHR, 2) wgrad_pipe_kernel(const WgradPara
         constexpr int LO = decltype(loc)::value, HIX = decltype(hic)::value;
 #pragma unroll
         for (int k = LO; k < HIX; ++k) acc[k >> 1][k & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[k >> 1], f.b[k & 1], acc[k >> 1][k & 1], 0, 0, 0);
-        if constexpr (BIAS && HIX == 8) {     // bias gradient: column sums of the dy fragments (the MFMA operand holds 8 pixels of one co per lane)
+        if constexpr (BIAS && LO == 0) {     // bias gradient: column sums of the dy fragments (the MFMA operand holds 8 pixels of one co per lane)
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 const s16x4 *h = reinterpret_cast<const s16x4 *>(&f.a[t]);
@@ -208,6 +220,7 @@ __global__ void __launch_bounds__(wp::NTHR, 2) wgrad_pipe_kernel(const WgradPara
     };
     using I0 = std::integral_constant<int, 0>;
     using I1 = std::integral_constant<int, 1>;
+    using I4 = std::integral_constant<int, 4>;
     using I6 = std::integral_constant<int, 6>;
     using I7 = std::integral_constant<int, 7>;
     using I8 = std::integral_constant<int, 8>;
@@ -232,61 +245,100 @@ __global__ void __launch_bounds__(wp::NTHR, 2) wgrad_pipe_kernel(const WgradPara
         nxt = nxt + 1 == NST ? 0 : nxt + 1;
         lbuf = lbuf + 1 == NST ? 0 : lbuf + 1;
     };
-    auto step = [&](auto fullc, auto morec) {
-        constexpr bool FULL = decltype(fullc)::value, MORE = decltype(morec)::value;
+#ifdef IGEMM_STAMPS
+    long stamp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define WSTAMP(i) do { if (p.dbg && it == p.dbg_it) { __builtin_amdgcn_sched_barrier(0); stamp[i] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } } while (0)
+#else
+#define WSTAMP(i) do { } while (0)
+#endif
+    int it = 0;
+    // One stage = two 16-pixel sub-steps of eight MFMAs.  Each sub-step has a "read" half (four MFMAs with the 12 transposing
+    // reads of the next sub-step and the address arithmetic behind them) and a "DMA" half (four MFMAs with two LDS-DMA between
+    // them).  The two waves of a SIMD share its matrix pipe and the per-stage barrier starts them in lock step, so group A
+    // (waves 0-3) runs read half, DMA half and group B (SWAP) DMA half, read half: one wave's non-MFMA issue slots then face the
+    // other's MFMAs instead of its stalls (stamps: each wave is busy ~1070 cycles per stage, 512 of them issuing MFMAs).
+    auto step = [&](auto fullc, auto morec, auto swapc) {
+        constexpr bool FULL = decltype(fullc)::value, MORE = decltype(morec)::value, SWAP = decltype(swapc)::value;
+        WSTAMP(0);
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
-        // sub-step 0: the 12 transposing reads of sub-step 1 behind the first six MFMAs, then the four LDS-DMA of stage
-        // it + D (inline asm: placed by hand, two behind each of the last MFMAs)
-        rd(cur, 1, f1);
-        const bf16_t *sa[2], *sx[2];
+        WSTAMP(1);
+        unsigned sa[2], sx[2];
         if constexpr (FULL) stage_addr(sa, sx);
-        mm(f0, I0{}, I6{});
+        auto read_half = [&](WPFrag &cur_f, auto loc, auto hic, auto dordc, int rbuf, int rsub, WPFrag &dst) {
+            constexpr bool DO = decltype(dordc)::value;
+            if constexpr (DO) rd(rbuf, rsub, dst);
+            mm(cur_f, loc, hic);
+            if constexpr (DO) {
 #pragma unroll
-        for (int k = 0; k < 6; ++k) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-            if constexpr (FULL) __builtin_amdgcn_sched_group_barrier(0x006, 8, 0);     // address arithmetic of the LDS-DMA below
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        if constexpr (FULL) {
-            stage_issue(lbuf, 0, sa[0], sx[0]);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        mm(f0, I6{}, I7{});
-        __builtin_amdgcn_sched_barrier(0);
-        if constexpr (FULL) {
-            stage_issue(lbuf, 1, sa[1], sx[1]);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        mm(f0, I7{}, I8{});
-        __builtin_amdgcn_sched_barrier(0);
-        // sub-step 1: the reads of the next stage's sub-step 0 behind the MFMAs
-        if constexpr (MORE) rd(nxt, 0, f0);
-        mm(f1, I0{}, I8{});
-        if constexpr (MORE) {
-#pragma unroll
-            for (int k = 0; k < 6; ++k) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                for (int k = 0; k < 4; ++k) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+                    if constexpr (FULL) __builtin_amdgcn_sched_group_barrier(0x006, 6, 0);
+                }
             }
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        auto dma_half = [&](WPFrag &cur_f, auto loc, int i) {
+            constexpr int LO = decltype(loc)::value;
+            if constexpr (FULL) {
+                issue_dy(lbuf, i, sa[i]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            mm(cur_f, std::integral_constant<int, LO>{}, std::integral_constant<int, LO + 2>{});
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (FULL) {
+                issue_x(lbuf, i, sx[i]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            mm(cur_f, std::integral_constant<int, LO + 2>{}, std::integral_constant<int, LO + 4>{});
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        if constexpr (!SWAP) {
+            read_half(f0, I0{}, I4{}, std::true_type{}, cur, 1, f1);
+            WSTAMP(2);
+            dma_half(f0, I4{}, 0);
+            WSTAMP(3);
+            read_half(f1, I0{}, I4{}, std::integral_constant<bool, MORE>{}, nxt, 0, f0);
+            WSTAMP(4);
+            dma_half(f1, I4{}, 1);
+            WSTAMP(5);
+        } else {
+            dma_half(f0, I0{}, 0);
+            WSTAMP(2);
+            read_half(f0, I4{}, I8{}, std::true_type{}, cur, 1, f1);
+            WSTAMP(3);
+            dma_half(f1, I0{}, 1);
+            WSTAMP(4);
+            read_half(f1, I4{}, I8{}, std::integral_constant<bool, MORE>{}, nxt, 0, f0);
+            WSTAMP(5);
         }
-        __builtin_amdgcn_sched_barrier(0);
+        WSTAMP(6);
     };
-    int it = 0;
+    auto loop = [&](auto swapc) {
     for (; it + D < nst; ++it) {                      // stages that issue the DMA of stage it + D
         wp_wait_vmcnt<(D - 2) * LOADS>();
-        step(std::true_type{}, std::true_type{});
+        step(std::true_type{}, std::true_type{}, swapc);
         adv();
     }
     for (; it + 1 < nst; ++it) {                      // nothing left to stage
         if (nst - 2 - it >= D - 2) wp_wait_vmcnt<(D - 2) * LOADS>();
         else wp_wait_vmcnt<0>();
-        step(std::false_type{}, std::true_type{});
+        step(std::false_type{}, std::true_type{}, swapc);
         adv();
     }
     wp_wait_vmcnt<0>();
-    step(std::false_type{}, std::false_type{});       // last stage: no further reads
+    step(std::false_type{}, std::false_type{}, swapc);       // last stage: no further reads
+    };
+    if (wave < NW / 2) loop(std::false_type{});
+    else loop(std::true_type{});
+#ifdef IGEMM_STAMPS
+    if (p.dbg && lane == 0 && blockIdx.x < 512) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) p.dbg[((long)blockIdx.x * 8 + wave) * 8 + i] = stamp[i];
+    }
+#endif
+#undef WSTAMP
 
     };
     if (do_bias) run(std::true_type{});
@@ -351,11 +403,15 @@ int wgrad_pipe_launch(const WgradParams &p, dim3 grid, hipStream_t s)
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
     if (!attr_done[dev]) {
-        hipError_t e = hipFuncSetAttribute((const void *)wgrad_pipe_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, wp::LDS_BYTES);
+        hipError_t e = hipFuncSetAttribute((const void *)wgrad_pipe_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, wp::LDS_BYTES);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void *)wgrad_pipe_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, wp::LDS_BYTES);
         if (e != hipSuccess) return fail((int)e, "yolo_wgrad: hipFuncSetAttribute(%d B LDS): %s", wp::LDS_BYTES, hipGetErrorString(e));
         attr_done[dev] = true;
     }
-    hipLaunchKernelGGL(wgrad_pipe_kernel, grid, dim3(wp::NTHR), wp::LDS_BYTES, s, p);
+    WgradParams q = p;
+    debug_stamp_target(&q.dbg, &q.dbg_it);
+    if (p.gW) hipLaunchKernelGGL(wgrad_pipe_kernel<true>, grid, dim3(wp::NTHR), wp::LDS_BYTES, s, q);
+    else hipLaunchKernelGGL(wgrad_pipe_kernel<false>, grid, dim3(wp::NTHR), wp::LDS_BYTES, s, q);
     return check_launch("yolo_wgrad (pipelined)");
 }
 

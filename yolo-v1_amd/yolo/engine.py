@@ -924,9 +924,10 @@ class Plan:
     @staticmethod
     def _wgrad_desc(L: Layer, g: Act, xin: Act, N: int) -> WgradDesc:
         """yolo_wgrad problem of conv layer L over N images of the gradient buffer g / the input buffer xin"""
-        # kernel variant: the 256 x 256 pipelined kernel (5) on the big deep layers, where the in-process A/B measured it 8-9 %
-        # faster (56x56 256 -> 512, 28x28 512 -> 1024: tools/time_wgrad.py); the 128 x 128 kernel (0) everywhere else
-        variant = 5 if (WGRAD_PIPE and L.K == 3 and L.stride == 1 and L.Cout >= 512 and L.Cin >= 256 and N * L.Hout * L.Wout >= 40000) else 0
+        # kernel variant: the 256 x 256 pipelined kernel (5) on the big deep layers, where the in-process A/B measured it 10-19 %
+        # faster (56x56 256 -> 512, 28x28 512 -> 1024, 14x14 1024 -> 1024: tools/time_wgrad.py); the 128 x 128 kernel (0) elsewhere
+        deep = (L.Cout >= 512 and L.Cin >= 256 and N * L.Hout * L.Wout >= 40000) or (L.Cout >= 1024 and L.Cin >= 1024 and N * L.Hout * L.Wout >= 12000)
+        variant = 5 if (WGRAD_PIPE and L.K == 3 and L.stride == 1 and deep) else 0
         if variant == 5 or (L.Hout >= 2 and L.Wout >= 2 and (L.stride > 1 or g.Hp * g.Wp >= 1.12 * L.Hout * L.Wout)):
             return WgradDesc(N * L.Hout * L.Wout, g.px_stride, xin.px_stride, L.Cout, L.Cin, L.K, L.K, L.pad, xin.row_stride, 0, 0, variant,
                              L.Wout, L.Hout, g.Hp * g.Wp, g.Wp * L.stride, L.stride, g.halo * g.Wp + g.halo)
