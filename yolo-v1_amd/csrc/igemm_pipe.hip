@@ -320,6 +320,9 @@ __global__ void __launch_bounds__(TCO * 2, 2) igemm_pipe_kernel(const IgemmParam
     float bias8[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) bias8[k] = has_bias && (co + k < p.Cout) ? p.bias[co + k] : 0.0f;
+    // 0: generic loop; 1 / 2: the straight-line fast paths below (bf16 output, no pool, no slabs, channel tile inside Cout)
+    const int fast_kind = (!p.out_fp32 && !p.pool && !p.slab_stride && co0 + TCO <= p.Cout && p.slope >= 0.0f && p.slope <= 1.0f)
+                              ? (p.epilogue == YOLO_EPI_BIAS_LRELU ? 1 : (p.epilogue == YOLO_EPI_MUL_DLRELU ? 2 : 0)) : 0;
     void *const outp = p.slab_stride ? (void *)(reinterpret_cast<float *>(p.out) + (long)blockIdx.y * p.slab_stride) : p.out;
 
     auto pack8 = [](const float (&v)[8]) {
@@ -379,6 +382,60 @@ __global__ void __launch_bounds__(TCO * 2, 2) igemm_pipe_kernel(const IgemmParam
                     *reinterpret_cast<uint4 *>(full + tab[4 * px + 2] + co) = pack8(v);
                 }
             }
+            continue;
+        }
+        if (fast_kind) {
+            // the two common epilogues -- bias + LeakyReLU (forward) and x LeakyReLU'(aux) (data gradient), bf16 out, whole channel
+            // tile inside Cout -- as straight-line code: all LDS reads (and the aux loads) of the pass first, then arithmetic and
+            // stores.  The generic loop below takes ~15 k cycles per tile (in-kernel stamps): it walks a chain of run-time branches
+            // per pixel and exposes the LDS latency seven times per pass.
+            constexpr int NI = PPX / PX_PER_STEP;           // 7 pixels per thread and pass
+            auto fast = [&](auto kindc) {
+                constexpr int KIND = decltype(kindc)::value;    // 1: bias + LeakyReLU, 2: multiply by LeakyReLU'(aux)
+                const int lp0 = tid / CCH;
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {          // two batches (4 + 3 pixels): the other group's accumulators are still live
+                    constexpr int NB = 4;
+                    long ob[NB];
+                    f32x4 lo[NB], hi[NB];
+                    uint4 ax[NB];
+#pragma unroll
+                    for (int i = 0; i < NB; ++i) {
+                        const int it = half * NB + i;
+                        const int lp = lp0 + it * PX_PER_STEP;
+                        const bool in = it < NI && lp < ppx_q;
+                        const int px = pbase + (in ? lp : 0);
+                        ob[i] = in ? tab[4 * px + 1] : -1;
+                        lo[i] = *reinterpret_cast<const f32x4 *>(ep + (in ? lp : 0) * EP + cc * 8);
+                        hi[i] = *reinterpret_cast<const f32x4 *>(ep + (in ? lp : 0) * EP + cc * 8 + 4);
+                        if constexpr (KIND == 2) {
+                            if (ob[i] >= 0) ax[i] = *reinterpret_cast<const uint4 *>(p.aux + tab[4 * px + 2] + co);
+                        }
+                    }
+#pragma unroll
+                    for (int i = 0; i < NB; ++i) {
+                        if (ob[i] < 0) continue;
+                        float v[8] = {lo[i][0], lo[i][1], lo[i][2], lo[i][3], hi[i][0], hi[i][1], hi[i][2], hi[i][3]};
+                        if constexpr (KIND == 1) {
+#pragma unroll
+                            for (int k = 0; k < 8; ++k) {
+                                const float t = v[k] + bias8[k];
+                                v[k] = fmaxf(t, t * p.slope);           // LeakyReLU for 0 <= slope <= 1
+                            }
+                        } else {
+                            const unsigned yy[4] = {ax[i].x, ax[i].y, ax[i].z, ax[i].w};
+#pragma unroll
+                            for (int k = 0; k < 8; ++k) {
+                                const float a = __uint_as_float((k & 1) ? (yy[k >> 1] & 0xffff0000u) : (yy[k >> 1] << 16));
+                                v[k] = a > 0.0f ? v[k] : v[k] * p.slope;
+                            }
+                        }
+                        *reinterpret_cast<uint4 *>(reinterpret_cast<bf16_t *>(p.out) + ob[i] + co) = pack8(v);
+                    }
+                }
+            };
+            if (fast_kind == 1) fast(std::integral_constant<int, 1>{});
+            else fast(std::integral_constant<int, 2>{});
             continue;
         }
 #pragma unroll 2
