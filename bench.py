@@ -133,7 +133,7 @@ def main():
 
     import synth
     from yolo import YOLOLoss, YOLOv1, engine, ops
-    from yolo.parallel import OverlappedGradAllReduce
+    from yolo.parallel import make_grad_reducer
 
     B = a.batch
     torch.manual_seed(0)
@@ -225,7 +225,7 @@ def main():
         opt = Adam(model.parameters(), lr=1e-4, weight_decay=5e-4, max_grad_norm=10.0)  # clip_grad_norm_(10) + Adam fused
         opt.attach_plan(model.hip_plan())   # Adam also refreshes the bf16 operands of the Linear layers
         # data parallel: gradient arena + all-reduce overlapped with the backward pass (FC1's 822 MB first)
-        ar = OverlappedGradAllReduce(model.hip_plan(), dev) if use_dist else None
+        ar = make_grad_reducer(model, dev) if use_dist else None      # the reducer the shipped training loop uses
 
         def step():
             opt.zero_grad(set_to_none=True)
@@ -237,7 +237,7 @@ def main():
 
         ksteps = max(3, a.steps // 2)
         dt_t = timed_steps(step, ksteps, max(2, a.warmup // 2), world)
-        if a.layers and rank == 0:
+        if a.layers and rank == 0 and world == 1:
             engine.TIMERS = []
             step()
             torch.cuda.synchronize()
@@ -245,7 +245,7 @@ def main():
                 ms = e0.elapsed_time(e1)
                 print(f"train {tag:16s} {kern:14s} {ms:8.3f} ms {flops / max(ms, 1e-9) / 1e9:9.1f} TFLOP/s", file=sys.stderr)
             engine.TIMERS = None
-        troof = kernel_rooflines(step) if rank == 0 else {}
+        troof = kernel_rooflines(step)      # on every rank: the step holds a collective when N > 1
         train = {"value": round(world * B * ksteps / dt_t, 1), "unit": "images/s", "ms_per_step": round(1e3 * dt_t / ksteps, 3),
                  "steps": ksteps, "global_batch": world * B,
                  "step_tflops": round(120.8e9 * world * B / (dt_t / ksteps) / 1e12, 1),

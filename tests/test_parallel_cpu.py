@@ -41,6 +41,15 @@ def _worker(rank, world, port, q):
     loss, _ = YOLOLoss()(model(x[sl]).view(-1, 7, 7, 30), t[sl])
     loss.backward()
     GradAllReduce(model.parameters(), big_bytes=1 << 12).all_reduce_mean()   # exercises both the big and the packed path
+    # the reducer the shipped training loop picks (training.train_epoch): plain GradAllReduce for CPU tensors / custom modules;
+    # averaging already-identical gradients must leave them unchanged
+    from yolo.parallel import make_grad_reducer
+    red = make_grad_reducer(model, "cpu")
+    assert type(red).__name__ == "GradAllReduce"
+    before = [p.grad.clone() for p in model.parameters()]
+    red.all_reduce_mean()
+    for a, p in zip(before, model.parameters()):
+        assert torch.allclose(a, p.grad, rtol=1e-6, atol=1e-8)
     q.put((rank, [p.grad.numpy().copy() for p in model.parameters()], [p.detach().numpy().copy() for p in model.parameters()]))
     dist.barrier()
     dist.destroy_process_group()
@@ -129,3 +138,60 @@ def test_overlapped_bucket_allreduce_gloo():
         want = base * ((1 + step) + (2 + step)) / 2          # mean over the two ranks
         for r in res:
             assert (abs(r[1][step] - want) < 1e-3).all()
+
+
+def _train_worker(rank, world, port, ckdir, q):
+    for p in (ROOT, os.path.join(ROOT, "yolo-v1_amd"), os.path.join(ROOT, "tests", "golden")):
+        sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from pathlib import Path
+    import synth
+    from torch.utils.data import DataLoader, TensorDataset
+    from yolo import YOLOLoss, training
+    from yolo.parallel import broadcast_parameters, shard_batch
+
+    class Net(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.body = _tiny_model()
+
+        def forward(self, x):
+            return self.body(x).view(-1, 7, 7, 30)
+
+    torch.manual_seed(50 + rank)
+    model = Net()
+    broadcast_parameters(model)
+    x = torch.from_numpy(synth.synth_normal((8, 3, 14, 14), 9))
+    t = torch.from_numpy(synth.synth_targets(8, 4))
+    sl = shard_batch(8, rank, world)
+    loader = DataLoader(TensorDataset(x[sl], t[sl]), batch_size=2)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    sched = torch.optim.lr_scheduler.MultiStepLR(opt, milestones=[10], gamma=0.1)
+    res = training.train(model, loader, loader, YOLOLoss(), opt, sched, "cpu", 2, Path(ckdir), save_frequency=1)
+    q.put((rank, float(res["final_train_loss"]), [p.detach().numpy().copy() for p in model.parameters()]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_trainer_two_ranks_write_checkpoints_once(tmp_path):
+    """the shipped training loop under torch.distributed (gloo, world 2): gradients are averaged by the reducer the loop picks,
+    ranks stay bit-identical, and ONLY rank 0 writes the checkpoint files -- atomically, no temp files left, loadable with
+    weights_only=True (round 1: every rank wrote the same paths concurrently)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_train_worker, args=(r, 2, port, str(tmp_path), q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=180) for _ in procs], key=lambda r: r[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for a, b in zip(res[0][2], res[1][2]):
+        assert (a == b).all()
+    names = sorted(os.listdir(tmp_path))
+    assert names == ["yolo_best.pth", "yolo_epoch_1.pth", "yolo_epoch_2.pth", "yolo_latest.pth"], names
+    ck = torch.load(tmp_path / "yolo_latest.pth", weights_only=True)
+    assert ck["epoch"] == 2 and "optimizer_state_dict" in ck
