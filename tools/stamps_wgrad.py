@@ -28,7 +28,7 @@ for item in synth.YOLOV1_BACKBONE_CFG:
     x = Act(N, h, h, ci, 1, dev); dy = Act(N, h, h, co, 1, dev)
     x.t.normal_(); dy.t.normal_()
     dwp = torch.zeros((co, k, k, ci), dtype=torch.float32, device=dev)
-    wd = WgradDesc(N * h * h, dy.px_stride, x.px_stride, co, ci, k, k, p, x.row_stride, 0, 0, 5, h, h, dy.Hp * dy.Wp, dy.Wp, 1, dy.Wp + 1)
+    wd = WgradDesc(N * h * h, dy.px_stride, x.px_stride, co, ci, k, k, p, x.row_stride, int(os.environ.get("SPLIT", "0")), 0, 5, h, h, dy.Hp * dy.Wp, dy.Wp, 1, dy.Wp + 1)
     buf = torch.zeros(512 * 64, dtype=torch.int64, device=dev)
     for _ in range(10):
         check(lib().yolo_wgrad(ctypes.byref(wd), x.p, dy.p, ptr(dwp), None, stream()))
@@ -38,6 +38,17 @@ for item in synth.YOLOV1_BACKBONE_CFG:
     torch.cuda.synchronize()
     check(lib().yolo_debug_stamps(None, 0))
     st = buf.cpu().view(512, 8, 8).double()
+    if stage < 0:      # whole-kernel sections: start | first stage landed | K loop done | bias atomics | output stored
+        ok = st[:, 0, 4] > 0
+        w = st[ok]
+        t0 = w[:, :, 0].min()
+        sec = w[:, :, 1:5] - w[:, :, 0:4]
+        print(f"layer {layer}: {int(ok.sum())} workgroups; stages per workgroup median {w[:, 0, 5].median().item():.0f}; median cycles")
+        print("  prologue (tables + first stage) %7.0f | K loop %8.0f (%5.0f per stage) | bias %6.0f | output %7.0f | whole %8.0f | start spread %7.0f end spread %7.0f"
+              % (sec[:, :, 0].median().item(), sec[:, :, 1].median().item(), (sec[:, :, 1] / w[:, :, 5:6].clamp(min=1)[:, 0:1, 0]).median().item(),
+                 sec[:, :, 2].median().item(), sec[:, :, 3].median().item(), (w[:, :, 4] - w[:, :, 0]).median().item(),
+                 (w[:, 0, 0].max() - t0).item(), (w[:, 0, 4].max() - w[:, 0, 4].min()).item()))
+        continue
     ok = st[:, 0, 6] > 0
     seg = (st[:, :, 1:7] - st[:, :, 0:6])[ok].reshape(-1, 6)
     print(f"layer {layer} stage {stage}: {int(ok.sum())} workgroups stamped; median cycles per wave")

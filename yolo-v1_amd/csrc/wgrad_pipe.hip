@@ -53,6 +53,13 @@ __global__ void __launch_bounds__(wp::NTHR, 2) wgrad_pipe_kernel(const WgradPara
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wco = wave >> 2, wci = wave & 3;           // 2 x 4 waves: 128 co x 64 ci each
+#ifdef IGEMM_STAMPS
+    long kstamp[8] = {0, 0, 0, 0, 0, 0, 0, 0};       // dbg_it < 0: whole-kernel sections instead of one stage
+#define KSTAMP(i) do { if (p.dbg && p.dbg_it < 0) { __builtin_amdgcn_sched_barrier(0); kstamp[i] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } } while (0)
+#else
+#define KSTAMP(i) do { } while (0)
+#endif
+    KSTAMP(0);
 
     const int ntap_tiles = (p.ntaps + p.tile_taps - 1) / p.tile_taps;
     const int nwg = p.n_co_tiles * p.n_ci_tiles * ntap_tiles;
@@ -237,6 +244,7 @@ __global__ void __launch_bounds__(wp::NTHR, 2) wgrad_pipe_kernel(const WgradPara
     else wp_wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
+    KSTAMP(1);
     WPFrag f0, f1;
     rd(0, 0, f0);
     int cur = 0, nxt = 1, lbuf = D;
@@ -332,8 +340,9 @@ __global__ void __launch_bounds__(wp::NTHR, 2) wgrad_pipe_kernel(const WgradPara
     };
     if (wave < NW / 2) loop(std::false_type{});
     else loop(std::true_type{});
+    KSTAMP(2);
 #ifdef IGEMM_STAMPS
-    if (p.dbg && lane == 0 && blockIdx.x < 512) {
+    if (p.dbg && p.dbg_it >= 0 && lane == 0 && blockIdx.x < 512) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) p.dbg[((long)blockIdx.x * 8 + wave) * 8 + i] = stamp[i];
     }
@@ -353,23 +362,28 @@ __global__ void __launch_bounds__(wp::NTHR, 2) wgrad_pipe_kernel(const WgradPara
         }
     }
 
+    KSTAMP(3);
     // ---- output through LDS, 64 co rows at a time ([64 co][256 ci] fp32 = 64 KB): accumulator layout of the 32x32 MFMA is
     // row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5), col = lane & 31
     const long ldw = (long)p.ntaps * p.Cin;
     const long col0 = p.tile_taps > 1 ? (long)tap0 * p.Cin : (long)tap0 * p.Cin + ci0;
     float *ot = reinterpret_cast<float *>(smem);
     const bool vec_ok = !atomic && (p.Cin & 3) == 0 && ((uintptr_t)p.dw & 15) == 0;
-    for (int h = 0; h < 4; ++h) {
+    // workgroups that add into the same tile (different pixel ranges) finish together: each starts at a different row block so
+    // that their atomics do not queue on the same addresses
+    const int rot = (int)((pbeg / BP) % 127);
+    auto pass = [&](auto hc) {          // 64 co rows h * 64 .. of the tile; h is static: the accumulators must stay in registers
+        constexpr int h = decltype(hc)::value;
         __syncthreads();   // (first pass: every wave is done reading the stage buffers)
         if (wco == (h >> 1)) {
 #pragma unroll
             for (int ii = 0; ii < 2; ++ii) {
-                const int i = (h & 1) * 2 + ii;
+                constexpr int i0 = (h & 1) * 2;
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
 #pragma unroll
                     for (int r = 0; r < 16; ++r)
-                        ot[(ii * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * TCI + wci * 64 + j * 32 + (lane & 31)] = acc[i][j][r];
+                        ot[(ii * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * TCI + wci * 64 + j * 32 + (lane & 31)] = acc[i0 + ii][j][r];
             }
         }
         __syncthreads();
@@ -383,7 +397,8 @@ __global__ void __launch_bounds__(wp::NTHR, 2) wgrad_pipe_kernel(const WgradPara
             }
         } else {
 #pragma unroll 4
-            for (int k = 0; k < 32; ++k) {
+            for (int k0 = 0; k0 < 32; ++k0) {
+                const int k = (k0 + (rot >> 2)) & 31;
                 const int idx = k * NTHR + tid, row = idx >> 8, c = idx & 255;
                 const int co = co0 + h * 64 + row;
                 if (co < p.Cout && c < col_lim) {
@@ -394,7 +409,25 @@ __global__ void __launch_bounds__(wp::NTHR, 2) wgrad_pipe_kernel(const WgradPara
                 }
             }
         }
+    };
+    for (int h0 = 0; h0 < 4; ++h0) {
+        switch ((h0 + rot) & 3) {
+        case 0: pass(std::integral_constant<int, 0>{}); break;
+        case 1: pass(std::integral_constant<int, 1>{}); break;
+        case 2: pass(std::integral_constant<int, 2>{}); break;
+        default: pass(std::integral_constant<int, 3>{}); break;
+        }
     }
+#ifdef IGEMM_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    KSTAMP(4);
+    if (p.dbg && p.dbg_it < 0 && lane == 0 && blockIdx.x < 512) {
+        kstamp[5] = (pend - pbeg + BP - 1) / BP;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) p.dbg[((long)blockIdx.x * 8 + wave) * 8 + i] = kstamp[i];
+    }
+#endif
+#undef KSTAMP
 }
 
 int wgrad_pipe_launch(const WgradParams &p, dim3 grid, hipStream_t s)

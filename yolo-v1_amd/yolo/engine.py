@@ -44,6 +44,8 @@ IGEMM_LAUNCHES = 0  # yolo_igemm launches so far (bench.py: launches per step of
 STEM_KERNEL = True  # 7x7/s2 stem through yolo_conv_stem7_fwd (False: the generic row-segment implicit GEMM; tests compare)
 STEM_POOL_BWD_FUSED = True  # backward of the pool + LeakyReLU behind the stem inside yolo_wgrad_stem7_pooled (False: separate pass)
 STRIDE2_CLASSES = True  # data gradient of a stride-2 3x3 conv as four parity-class convs over the non-zero gradient slots
+_SIDE_STREAMS: dict = {}
+WGRAD_STREAM = True  # backward: weight gradients run on a second HIP stream beside the data-gradient chain (they are off its critical path)
 WGRAD_PIPE = True  # weight gradient of the big deep 3x3 layers through wgrad_pipe.hip (yolo_wgrad_desc.variant = 5)
 FUSE_POOL = True   # inference: fold MaxPool2d(2,2) into the preceding conv's epilogue where the geometry allows
 
@@ -473,6 +475,15 @@ class Plan:
                                  self.arena[bv[li][0]:bv[li][1]].view_as(self.layers[li].bias), wv[li][0], wv[li][2])
                             for li in order}
         return self.arena
+
+    @staticmethod
+    def _side_stream(dev) -> "torch.cuda.Stream":
+        """the second stream of the backward pass (weight gradients): one per device, shared by all plans (kept outside the plan
+        objects, which are deep-copied with their modules)"""
+        key = torch.device(dev).index
+        if key not in _SIDE_STREAMS:
+            _SIDE_STREAMS[key] = torch.cuda.Stream(device=dev)
+        return _SIDE_STREAMS[key]
 
     def _layer_done(self, li: int):
         if self.arena is not None and self.on_grad_ready is not None:
@@ -973,19 +984,40 @@ class Plan:
         def flush():
             items = [ConvUnpackItem(dwp.data_ptr(), dw.data_ptr(), L.Cout, L.Cin, L.K, L.K) for (i, L, dwp, dw) in pending if self._multi_ok(L)]
             if items:
-                check(L_.yolo_unpack_conv_wgrads_multi((ConvUnpackItem * len(items))(*items), len(items), st), "unpack_conv_wgrads_multi")
+                check(L_.yolo_unpack_conv_wgrads_multi((ConvUnpackItem * len(items))(*items), len(items), stream()), "unpack_conv_wgrads_multi")
             for (i, L, dwp, dw) in pending:
                 if not self._multi_ok(L):
                     if L.first:
-                        check(L_.yolo_unpack_conv_wgrad(ptr(dwp), L.Cout, 3, 7, 7, 4, 8, ptr(dw), 0, st), "unpack")
+                        check(L_.yolo_unpack_conv_wgrad(ptr(dwp), L.Cout, 3, 7, 7, 4, 8, ptr(dw), 0, stream()), "unpack")
                     else:
-                        check(L_.yolo_unpack_conv_wgrad(ptr(dwp), L.Cout, L.Cin, L.K, L.K, L.Cin, L.K, ptr(dw), 0, st), "unpack")
+                        check(L_.yolo_unpack_conv_wgrad(ptr(dwp), L.Cout, L.Cin, L.K, L.K, L.Cin, L.K, ptr(dw), 0, stream()), "unpack")
                 self._layer_done(i)
             pending.clear()
 
         gout = gout.detach()
         if gout.dtype != torch.float32 or not gout.is_contiguous():
             gout = gout.float().contiguous()
+
+        # The data gradients form the chain every later layer waits for; a layer's weight gradient only needs that layer's output
+        # gradient and is first read by the optimizer.  The conv weight gradients (and their unpack passes / gradient-ready
+        # callbacks) therefore go to a second stream: their atomic epilogues, partial last rounds and prologues -- phases in which a
+        # kernel leaves the matrix cores idle -- overlap with the data-gradient kernels of the layers below, workgroup by workgroup.
+        main_t = torch.cuda.current_stream(dev)
+        side_t = self._side_stream(dev) if (WGRAD_STREAM and TIMERS is None) else None
+
+        class _on_side:
+            def __enter__(self_):
+                if side_t is None:
+                    return st
+                side_t.wait_stream(main_t)           # behind everything queued so far (this layer's output gradient)
+                self_.ctx = torch.cuda.stream(side_t)
+                self_.ctx.__enter__()
+                return stream()
+
+            def __exit__(self_, *exc):
+                if side_t is not None:
+                    self_.ctx.__exit__(*exc)
+                return False
 
         # what each layer's input activation is
         def input_of(li):
@@ -1099,53 +1131,56 @@ class Plan:
                 xin = input_of(li)
                 # ---- weight + bias gradient
                 dw, db = grad_tensors(li)
-                o = offs[("w", li)]
-                stem_direct = L.first and L.Cout == 64 and L.Hout % 8 == 0 and L.Wout % 16 == 0
-                if stem_direct:
-                    part = ws["misc"].get("stem_part")
-                    if part is None:
-                        part = torch.empty((768 * 14400,), dtype=torch.float32, device=dev)
-                        ws["misc"]["stem_part"] = part
-                    with _timed(f"conv{li}.wgrad", "wgrad", 2.0 * N * L.Hout * L.Wout * L.Cout * 147):
-                        if stem_dpool is not None:
-                            yf = ws["acts"][0]
-                            check(L_.yolo_wgrad_stem7_pooled(xin.p, yf.p, N, L.Hout, L.Wout, xin.img_stride, xin.row_stride, yf.img_stride, yf.row_stride,
-                                                             yf.interior_off(), stem_dpool.p, stem_dpool.img_stride, stem_dpool.row_stride,
-                                                             stem_dpool.interior_off(), self.SLOPE if L.lrelu else 1.0, ptr(dw), ptr(db), ptr(part),
-                                                             part.numel(), st), "wgrad_stem7_pooled")
-                        else:
-                            check(L_.yolo_wgrad_stem7(xin.p, g.p, N, L.Hout, L.Wout, xin.img_stride, xin.row_stride, g.img_stride, g.row_stride,
-                                                      g.interior_off(), ptr(dw), ptr(db), ptr(part), part.numel(), st), "wgrad_stem7")
-                    grads[li] = (dw, db)
-                    flush()
-                    self._layer_done(li)
-                elif L.first:
-                    xcol = ws["misc"].get("xcol")
-                    if xcol is None:
-                        xcol = Act(N, L.Hout, L.Wout, 7 * 32, 1, dev)
-                        ws["misc"]["xcol"] = xcol
-                    check(L_.yolo_im2col_rows(xin.p, xin.img_stride, xin.row_stride, xin.px_stride, 2, 7, 32, N, L.Hout, L.Wout, 1, xcol.p, st), "im2col_rows")
-                    dwp = scratch[o: o + L.Cout * 7 * 8 * 4]
-                    split = max(1, min(1024, g.slots // 4096))
-                    wd = WgradDesc(g.slots, g.px_stride, xcol.px_stride, L.Cout, 7 * 32, 1, 1, 0, xcol.row_stride, split, 0)
-                    with _timed(f"conv{li}.wgrad", "wgrad", 2.0 * N * L.Hout * L.Wout * L.Cout * 147):
-                        check(L_.yolo_wgrad(ctypes.byref(wd), xcol.p, g.p, ptr(dwp), ptr(db), st), "wgrad conv0")
-                else:
-                    dwp = scratch[o: o + L.Cout * L.K * L.K * L.Cin]
-                    # reduce over the layer's OUTPUT pixels only (not over every slot of the zero-haloed -- for stride 2
-                    # zero-stuffed -- gradient buffer, whose geometry the input buffer shares slot for slot)
-                    # (measured: worth it from 28x28 down and for stride 2; at 56x56 and above the halo is < 8 % of the slots
-                    # and the per-row coordinate arithmetic costs more than it saves)
-                    wd = self._wgrad_desc(L, g, xin, N)
-                    with _timed(f"conv{li}.wgrad", "wgrad", 2.0 * N * L.Hout * L.Wout * L.Cout * L.Cin * L.K * L.K):
-                        check(L_.yolo_wgrad(ctypes.byref(wd), xin.p, g.p, ptr(dwp), ptr(db), st), f"wgrad conv{li}")
-                if not stem_direct:
-                    grads[li] = (dw, db)
-                    pending.append((li, L, dwp, dw))
-                    if li == 0 or sum(t[2].numel() for t in pending) >= (16 << 20):
+                with _on_side() as wst:
+                    o = offs[("w", li)]
+                    stem_direct = L.first and L.Cout == 64 and L.Hout % 8 == 0 and L.Wout % 16 == 0
+                    if stem_direct:
+                        part = ws["misc"].get("stem_part")
+                        if part is None:
+                            part = torch.empty((768 * 14400,), dtype=torch.float32, device=dev)
+                            ws["misc"]["stem_part"] = part
+                        with _timed(f"conv{li}.wgrad", "wgrad", 2.0 * N * L.Hout * L.Wout * L.Cout * 147):
+                            if stem_dpool is not None:
+                                yf = ws["acts"][0]
+                                check(L_.yolo_wgrad_stem7_pooled(xin.p, yf.p, N, L.Hout, L.Wout, xin.img_stride, xin.row_stride, yf.img_stride, yf.row_stride,
+                                                                 yf.interior_off(), stem_dpool.p, stem_dpool.img_stride, stem_dpool.row_stride,
+                                                                 stem_dpool.interior_off(), self.SLOPE if L.lrelu else 1.0, ptr(dw), ptr(db), ptr(part),
+                                                                 part.numel(), wst), "wgrad_stem7_pooled")
+                            else:
+                                check(L_.yolo_wgrad_stem7(xin.p, g.p, N, L.Hout, L.Wout, xin.img_stride, xin.row_stride, g.img_stride, g.row_stride,
+                                                          g.interior_off(), ptr(dw), ptr(db), ptr(part), part.numel(), wst), "wgrad_stem7")
+                        grads[li] = (dw, db)
                         flush()
+                        self._layer_done(li)
+                    elif L.first:
+                        xcol = ws["misc"].get("xcol")
+                        if xcol is None:
+                            xcol = Act(N, L.Hout, L.Wout, 7 * 32, 1, dev)
+                            ws["misc"]["xcol"] = xcol
+                        check(L_.yolo_im2col_rows(xin.p, xin.img_stride, xin.row_stride, xin.px_stride, 2, 7, 32, N, L.Hout, L.Wout, 1, xcol.p, wst), "im2col_rows")
+                        dwp = scratch[o: o + L.Cout * 7 * 8 * 4]
+                        split = max(1, min(1024, g.slots // 4096))
+                        wd = WgradDesc(g.slots, g.px_stride, xcol.px_stride, L.Cout, 7 * 32, 1, 1, 0, xcol.row_stride, split, 0)
+                        with _timed(f"conv{li}.wgrad", "wgrad", 2.0 * N * L.Hout * L.Wout * L.Cout * 147):
+                            check(L_.yolo_wgrad(ctypes.byref(wd), xcol.p, g.p, ptr(dwp), ptr(db), wst), "wgrad conv0")
+                    else:
+                        dwp = scratch[o: o + L.Cout * L.K * L.K * L.Cin]
+                        # reduce over the layer's OUTPUT pixels only (not over every slot of the zero-haloed -- for stride 2
+                        # zero-stuffed -- gradient buffer, whose geometry the input buffer shares slot for slot)
+                        # (measured: worth it from 28x28 down and for stride 2; at 56x56 and above the halo is < 8 % of the slots
+                        # and the per-row coordinate arithmetic costs more than it saves)
+                        wd = self._wgrad_desc(L, g, xin, N)
+                        with _timed(f"conv{li}.wgrad", "wgrad", 2.0 * N * L.Hout * L.Wout * L.Cout * L.Cin * L.K * L.K):
+                            check(L_.yolo_wgrad(ctypes.byref(wd), xin.p, g.p, ptr(dwp), ptr(db), wst), f"wgrad conv{li}")
+                    if not stem_direct:
+                        grads[li] = (dw, db)
+                        pending.append((li, L, dwp, dw))
+                        if li == 0 or sum(t[2].numel() for t in pending) >= (16 << 20):
+                            flush()
                 # ---- data gradient
                 if li == 0:
+                    if side_t is not None:
+                        main_t.wait_stream(side_t)       # every weight gradient is final before anything that follows the backward pass
                     gx = None
                     if need_gx:
                         if L.first:
@@ -1626,7 +1661,7 @@ class ResNetPlan:
             for i in range(0, len(pending), 32):
                 items = [ConvUnpackItem(dwp.data_ptr(), dw.data_ptr(), c.out_channels, c.in_channels, c.kernel_size[0], c.kernel_size[1])
                          for (c, dwp, dw) in pending[i: i + 32]]
-                check(L_.yolo_unpack_conv_wgrads_multi((ConvUnpackItem * len(items))(*items), len(items), st), "unpack_conv_wgrads_multi")
+                check(L_.yolo_unpack_conv_wgrads_multi((ConvUnpackItem * len(items))(*items), len(items), stream()), "unpack_conv_wgrads_multi")
             pending.clear()
 
         def bn_bwd(u, dy: Act, store_masked: bool) -> Act:
