@@ -42,6 +42,10 @@ const char *yolo_hip_last_error(void);
  * (int64, device memory of 512 * 64 entries; NULL switches it off).  The product library compiles no stamps and returns
  * YOLO_E_UNSUPPORTED for a non-NULL buffer.  tools/stamps_igemm.py reads them. */
 int yolo_debug_stamps(void *buf, int k_iter);
+/* A non-blocking HIP stream on the current device: of the lowest scheduling priority the device offers (low != 0) or of the
+ * default one.  For work off the critical path (weight gradients beside the data-gradient chain, a deferred optimizer pass):
+ * the dispatcher then prefers the main chain's workgroups.  The stream lives until the process ends. */
+int yolo_stream_create(int low, yolo_stream_t *out);
 
 /* ---------------------------------------------------------------------------------------------
  * Post-processing: S x S x B box decode, pairwise IoU, per-image NMS.  fp64 arithmetic on fp32

@@ -6,7 +6,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "yolo-v1_amd")); sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
 import torch
 import synth
-from yolo import YOLOv1, YOLOLoss, engine
+from yolo import YOLOv1, YOLOLoss, engine, optim
 from yolo.optim import Adam
 
 name, _, vals = sys.argv[1].partition("=")
@@ -34,7 +34,7 @@ for _ in range(5):
 res = {repr(v): [] for v in vals}
 for rnd in range(3):
     for v in vals:
-        setattr(engine, name, v)
+        setattr(optim if name.startswith("optim.") else engine, name.split(".")[-1], v)
         for _ in range(2):
             step()
         torch.cuda.synchronize()

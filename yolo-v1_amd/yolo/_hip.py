@@ -93,6 +93,7 @@ NMS_INFERENCE, NMS_METRICS = 0, 1
 _SIGS = {
     "yolo_hip_abi_version": [],
     "yolo_debug_stamps": [c_void_p, c_int],
+    "yolo_stream_create": [c_int, ctypes.POINTER(c_void_p)],
     "yolo_decode": [c_void_p, c_int, c_int, c_int, c_int, c_double, c_void_p, c_void_p, c_void_p],
     "yolo_decode_gt": [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p],
     "yolo_nms": [c_void_p, c_void_p, c_int, c_int, c_double, c_int, c_void_p, c_void_p, c_void_p],
@@ -190,6 +191,14 @@ def ptr(t) -> c_void_p:
 def stream() -> c_void_p:
     """The current PyTorch HIP stream as hipStream_t."""
     return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def side_stream(device, low: bool = True) -> "torch.cuda.Stream":
+    """a second HIP stream on ``device`` (lowest scheduling priority if ``low``), wrapped for torch's stream / event calls"""
+    with torch.cuda.device(device):
+        h = c_void_p()
+        check(lib().yolo_stream_create(1 if low else 0, ctypes.byref(h)), "yolo_stream_create")
+        return torch.cuda.ExternalStream(h.value, device=device)
 
 
 def require_cuda(*tensors) -> None:

@@ -45,6 +45,7 @@ STEM_KERNEL = True  # 7x7/s2 stem through yolo_conv_stem7_fwd (False: the generi
 STEM_POOL_BWD_FUSED = True  # backward of the pool + LeakyReLU behind the stem inside yolo_wgrad_stem7_pooled (False: separate pass)
 STRIDE2_CLASSES = True  # data gradient of a stride-2 3x3 conv as four parity-class convs over the non-zero gradient slots
 _SIDE_STREAMS: dict = {}
+SIDE_LOW = True      # ... of the lowest scheduling priority: the dispatcher prefers the data-gradient chain (12.73 -> 12.55 ms per step)
 WGRAD_STREAM = True  # backward: weight gradients run on a second HIP stream beside the data-gradient chain (they are off its critical path)
 WGRAD_PIPE = True  # weight gradient of the big deep 3x3 layers through wgrad_pipe.hip (yolo_wgrad_desc.variant = 5)
 FUSE_POOL = True   # inference: fold MaxPool2d(2,2) into the preceding conv's epilogue where the geometry allows
@@ -482,7 +483,7 @@ class Plan:
         objects, which are deep-copied with their modules)"""
         key = torch.device(dev).index
         if key not in _SIDE_STREAMS:
-            _SIDE_STREAMS[key] = torch.cuda.Stream(device=dev)
+            _SIDE_STREAMS[key] = _hip.side_stream(torch.device(dev), low=SIDE_LOW)
         return _SIDE_STREAMS[key]
 
     def _layer_done(self, li: int):
@@ -1006,8 +1007,11 @@ class Plan:
         side_t = self._side_stream(dev) if (WGRAD_STREAM and TIMERS is None) else None
 
         class _on_side:
+            def __init__(self_, enabled=True):
+                self_.on = enabled and side_t is not None
+
             def __enter__(self_):
-                if side_t is None:
+                if not self_.on:
                     return st
                 side_t.wait_stream(main_t)           # behind everything queued so far (this layer's output gradient)
                 self_.ctx = torch.cuda.stream(side_t)
@@ -1015,7 +1019,7 @@ class Plan:
                 return stream()
 
             def __exit__(self_, *exc):
-                if side_t is not None:
+                if self_.on:
                     self_.ctx.__exit__(*exc)
                 return False
 
