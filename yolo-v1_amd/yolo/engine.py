@@ -57,6 +57,27 @@ def _igemm(L_, d, inp, w, bias, aux, out, st, what):
     check(L_.yolo_igemm(ctypes.byref(d), inp, w, bias, aux, out, st), what)
 
 
+class _on_side_stream:
+    """``with _on_side_stream(main, side) as st:`` -- work issued inside goes to ``side`` (None: stays on ``main``), behind everything
+    queued on ``main`` so far; ``st`` is the hipStream_t to launch on.  The caller joins with ``main.wait_stream(side)``."""
+
+    def __init__(self, main_t, side_t):
+        self.main_t, self.side_t = main_t, side_t
+
+    def __enter__(self):
+        if self.side_t is None:
+            return ctypes.c_void_p(self.main_t.cuda_stream)
+        self.side_t.wait_stream(self.main_t)
+        self.ctx = torch.cuda.stream(self.side_t)
+        self.ctx.__enter__()
+        return ctypes.c_void_p(self.side_t.cuda_stream)
+
+    def __exit__(self, *exc):
+        if self.side_t is not None:
+            self.ctx.__exit__(*exc)
+        return False
+
+
 class _timed:
     def __init__(self, tag: str, kernel: str, flops: float = 0.0):
         self.tag, self.kernel, self.flops = tag, kernel, flops
@@ -1006,22 +1027,8 @@ class Plan:
         main_t = torch.cuda.current_stream(dev)
         side_t = self._side_stream(dev) if (WGRAD_STREAM and TIMERS is None) else None
 
-        class _on_side:
-            def __init__(self_, enabled=True):
-                self_.on = enabled and side_t is not None
-
-            def __enter__(self_):
-                if not self_.on:
-                    return st
-                side_t.wait_stream(main_t)           # behind everything queued so far (this layer's output gradient)
-                self_.ctx = torch.cuda.stream(side_t)
-                self_.ctx.__enter__()
-                return stream()
-
-            def __exit__(self_, *exc):
-                if self_.on:
-                    self_.ctx.__exit__(*exc)
-                return False
+        def _on_side():
+            return _on_side_stream(main_t, side_t)
 
         # what each layer's input activation is
         def input_of(li):
@@ -1660,8 +1667,16 @@ class ResNetPlan:
             tot += _round_up(c.weight.numel(), 64)
         scratch = torch.zeros(tot, dtype=torch.float32, device=dev)
         pending = []
+        # weight gradients (and their unpack passes) on the low-priority second stream, beside the BatchNorm-backward / data-gradient
+        # chain (Plan.backward does the same): the chain's HBM-bound BatchNorm passes and the MFMA-bound weight gradients mix well
+        main_t = torch.cuda.current_stream(dev)
+        side_t = Plan._side_stream(dev) if (WGRAD_STREAM and TIMERS is None) else None
 
         def flush():
+            with _on_side_stream(main_t, side_t):
+                _flush()
+
+        def _flush():
             for i in range(0, len(pending), 32):
                 items = [ConvUnpackItem(dwp.data_ptr(), dw.data_ptr(), c.out_channels, c.in_channels, c.kernel_size[0], c.kernel_size[1])
                          for (c, dwp, dw) in pending[i: i + 32]]
@@ -1698,9 +1713,10 @@ class ResNetPlan:
                                Wout, Hout, dz.Hp * dz.Wp, dz.Wp * s, s, dz.halo * dz.Wp + dz.halo)
             else:
                 wd = WgradDesc(dz.slots, dz.px_stride, xin.px_stride, conv.out_channels, conv.in_channels, k, k, p, xin.row_stride, 0, 0)
-            with _timed(f"{u['tag']}.wgrad", "wgrad", 2.0 * N * Hout * Wout * conv.out_channels * conv.in_channels * k * k):
-                check(L_.yolo_wgrad(ctypes.byref(wd), xin.p, dz.p, ptr(dwp), None, st), f"wgrad {u['tag']}")
             dw = torch.empty_like(conv.weight, dtype=torch.float32)
+            with _on_side_stream(main_t, side_t) as wst:
+                with _timed(f"{u['tag']}.wgrad", "wgrad", 2.0 * N * Hout * Wout * conv.out_channels * conv.in_channels * k * k):
+                    check(L_.yolo_wgrad(ctypes.byref(wd), xin.p, dz.p, ptr(dwp), None, wst), f"wgrad {u['tag']}")
             grads[conv.weight] = dw
             pending.append((conv, dwp, dw))
 
@@ -1769,6 +1785,8 @@ class ResNetPlan:
         check(L_.yolo_wgrad_stem7(xin.p, dz0.p, N, y0.H, y0.W, xin.img_stride, xin.row_stride, dz0.img_stride, dz0.row_stride, dz0.interior_off(),
                                   ptr(dw), ptr(self._stem_db), ptr(part), part.numel(), st), "wgrad_stem7")
         grads[conv.weight] = dw
+        if side_t is not None:
+            main_t.wait_stream(side_t)          # every weight gradient is final before the pass returns
         return grads
 
     def _act(self, key, N, H, W, C, halo, dev):
