@@ -79,7 +79,7 @@ def kernel_rooflines(fn, reps=2):
         d[2] += 1
     engine.TIMERS = None
     names = {"igemm": "igemm_kernel / igemm_pipe_kernel (implicit GEMM: conv / Linear forward and data gradient)",
-             "wgrad": "wgrad_kernel (weight gradient, ds_read_b64_tr_b16 operands)", "stem": "stem_fwd_kernel (7x7/s2 stem)"}
+             "wgrad": "wgrad_kernel / wgrad_pipe_kernel (weight gradient, ds_read_b64_tr_b16 operands; each launch timed alone -- the step itself runs them on a second stream beside the data gradients)", "stem": "stem_fwd_kernel (7x7/s2 stem)"}
     out = {}
     for kern, (ms, fl, n) in agg.items():
         if fl <= 0 or kern not in names:

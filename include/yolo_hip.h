@@ -143,7 +143,12 @@ typedef struct yolo_igemm_desc {
     int32_t pool2;          /* 1: fuse MaxPool2d(2,2) into the epilogue (conv -> LeakyReLU -> pool, models.py:49-55):
                                Ho/Wo stay the CONV output size, out_* address the pooled map [Ho/2][Wo/2];
                                2: as 1, and the UN-pooled activation is also written, to `aux` with the aux_* strides
-                               (training keeps it for the backward pass)                                       */
+                               (training keeps it for the backward pass);
+                               3: as 1, and `aux` receives the ARG-MAX CODES instead: uint16 per (pooled pixel, 8 channels)
+                               at index (pooled element address + channel) / 8 -- a buffer of the pooled map's geometry
+                               with an eighth of its elements -- 2 bits per channel = window position 2*dy + dx of the
+                               first maximum of the activations as stored.  With the pooled map that is all the backward
+                               pass needs (yolo_maxpool2_bwd_codes): the un-pooled activation is never written       */
     int32_t w_blocked;      /* 1: w is in the panel layout of yolo_pack_fc_weight_blocked (Linear layers)      */
     int32_t tile_order;     /* 0 = heuristic; 1 = channel tiles fastest; 2 = pixel tiles fastest inside an XCD's range   */
     int32_t tile_hint;      /* 0 = let the library pick the tile configuration; 1: 128x128, 2: 256x128
@@ -254,6 +259,11 @@ int yolo_maxpool3s2_bwd(const yolo_pool_desc *d, const void *x_bf16, const void 
 int yolo_maxpool2_fwd(const yolo_pool_desc *d, const void *x_bf16, void *y_bf16, yolo_stream_t stream);
 int yolo_maxpool2_bwd_lrelu(const yolo_pool_desc *d, const void *yfull_bf16, const void *dpool_bf16,
                             float slope, void *dz_bf16, yolo_stream_t stream);
+/* The same gradient from the POOLED activation (geometry of dpool) and the arg-max codes a fused conv + pool epilogue left
+ * (yolo_igemm pool2 = 3, yolo_conv_stem7_fwd codes): codes[(pooled element address) / 8] = uint16, 2 bits per channel.  The
+ * un-pooled activation is not read -- training never stores it (models.py:49-55: conv -> LeakyReLU -> MaxPool2d). */
+int yolo_maxpool2_bwd_codes(const yolo_pool_desc *d, const void *ypool_bf16, const void *codes_u16, const void *dpool_bf16,
+                            float slope, void *dz_bf16, yolo_stream_t stream);
 
 /* ---- layout / precision conversion at the boundary to PyTorch-layout fp32 tensors ------------- */
 
@@ -287,7 +297,9 @@ int yolo_unpack_conv_wgrad(const float *dw_packed, int Cout, int Cin, int KH, in
  * once in LDS and the 4x overlap of neighbouring pixels' 7 x 8 windows is resolved by the MFMA operand read addresses
  * (the generic yolo_igemm gathers every window from L2: 448 B per output pixel).  Ho % 8 == 0, Wo % 16 == 0.
  * out_full (pool2 = 1 only, may be NULL): the un-pooled activation is written as well -- training needs it for the
- * backward of the pool and of the LeakyReLU -- so that the separate pooling pass disappears there too. */
+ * backward of the pool and of the LeakyReLU -- so that the separate pooling pass disappears there too.
+ * pool2 = 3: out_full receives the ARG-MAX CODES instead (uint16 per pooled pixel and 8 channels at (pooled element address) / 8,
+ * 2 bits per channel, as yolo_igemm pool2 = 3; full_* unused): with the pooled map that is all the backward pass needs. */
 int yolo_conv_stem7_fwd(const void *x_nhwc4_bf16, const void *w_packed_bf16, const float *bias, int N, int Ho, int Wo,
                         long x_img_stride, int x_row_stride, float slope, int pool2, void *out_bf16,
                         long out_img_stride, int out_row_stride, int out_off, void *out_full_bf16,
@@ -309,6 +321,13 @@ int yolo_wgrad_stem7_pooled(const void *x_nhwc4_bf16, const void *y_full_bf16, i
                             int x_row_stride, long y_img_stride, int y_row_stride, int y_off, const void *dpool_bf16,
                             long dp_img_stride, int dp_row_stride, int dp_off, float slope, float *dw_oihw, float *db,
                             float *scratch, long scratch_elems, yolo_stream_t stream);
+/* ... and from what a stem forward with pool2 = 3 left instead of the un-pooled activation: y_pooled (geometry of dpool: the
+ * dp_* strides address both) and the arg-max codes (uint16 at (pooled element address) / 8).  Reads 154 MB instead of 514 MB at
+ * batch 64; same results bit for bit. */
+int yolo_wgrad_stem7_codes(const void *x_nhwc4_bf16, const void *y_pooled_bf16, const void *codes_u16, int N, int Ho, int Wo,
+                           long x_img_stride, int x_row_stride, const void *dpool_bf16, long dp_img_stride, int dp_row_stride,
+                           int dp_off, float slope, float *dw_oihw, float *db, float *scratch, long scratch_elems,
+                           yolo_stream_t stream);
 /* Whole-model forms of the two calls above: every conv layer of the model in ONE launch (LDS-tiled,
  * all HBM accesses in runs of >= 128 B).  Layers need Cout % 64 == 0 (unpack: % 4), Cin % 64 == 0,
  * KH*KW <= 9 and no padding (Cinp = Cin, KWp = KW); either output of a pack item may be NULL. */

@@ -168,6 +168,27 @@ __global__ void __launch_bounds__(WCO * WPX * 64, 2) igemm_kernel(const IgemmPar
         }
     }
 
+    // Epilogues that read a second tensor (residual add / LeakyReLU' gate), bf16 output, small tiles (the HBM-bound thin-K layers):
+    // the aux vectors of a pass are fetched in front of that pass's LDS staging, so that their HBM latency overlaps the staging
+    // and its barriers instead of being paid pixel by pixel inside the store loop (ResNet-50 inference at batch 64: 6.28 -> 5.99 ms;
+    // fetching them already in front of the K loop was slower, 6.16 ms -- they then delay the operand stream).
+    constexpr int E_CCH = TCO / 8, E_PXS = NTHR / E_CCH, E_PPX = Cfg::PPX;
+    constexpr int NIT = (E_PPX + E_PXS - 1) / E_PXS;
+    constexpr bool CAN_PREFETCH = NIT <= 4 && !UNEVEN && !STATS && TCO * TPX <= 128 * 128;   // (the big tiles have no registers to spare)
+    const bool aux_fast = CAN_PREFETCH && (p.epilogue == YOLO_EPI_BIAS_ADD_LRELU || p.epilogue == YOLO_EPI_MUL_DLRELU) && gridDim.y == 1 && !p.pool &&
+                          !p.out_fp32 && co0 + (tid % E_CCH) * 8 + 8 <= p.Cout;
+    uint4 axv[CAN_PREFETCH ? NIT : 1];
+    long axo[CAN_PREFETCH ? NIT : 1];
+    auto aux_fetch = [&](int q) {
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int lp = tid / E_CCH + it * E_PXS;
+            const int px = q * E_PPX + (lp < E_PPX ? lp : 0);
+            axo[it] = lp < E_PPX ? tab[4 * px + 1] : -1;
+            axv[it] = axo[it] >= 0 ? *reinterpret_cast<const uint4 *>(p.aux + tab[4 * px + 2] + co0 + (tid % E_CCH) * 8) : uint4{0u, 0u, 0u, 0u};
+        }
+    };
+
     // ---- K range of this split.  Single-tap problems (Linear layers) interleave the splits: split y
     // takes K steps y, y+S, y+2S, ... so that at any moment the S workgroups of one output tile stream
     // ADJACENT 16-KB pieces of the weight matrix (DRAM-page friendly) instead of S far-apart ranges.
@@ -423,6 +444,9 @@ __global__ void __launch_bounds__(WCO * WPX * 64, 2) igemm_kernel(const IgemmPar
 
     for (int q = 0; q < WPX; ++q) {
         if (q > 0) __syncthreads();   // the previous slab has been streamed out
+        if constexpr (CAN_PREFETCH) {
+            if (aux_fast) aux_fetch(q);
+        }
         if (wpx == q) {
 #pragma unroll
             for (int i = 0; i < MT; ++i)
@@ -469,12 +493,35 @@ __global__ void __launch_bounds__(WCO * WPX * 64, 2) igemm_kernel(const IgemmPar
                 const long ob = tab[4 * (pbase + l00) + 1];
                 if (ob < 0 || co >= p.Cout) continue;
                 float v[8];
+                if (p.pool == 3) {
+                    // pool2 = 3 (training): the pooled map + the window position of every maximum (2 bits per channel, one ushort
+                    // per 8 channels), compared on the activations as stored (bf16), first maximum in (0,0),(0,1),(1,0),(1,1) order
+                    unsigned code = 0;
 #pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    const float a = ep[l00 * Cfg::EP + cc * 8 + k], b = ep[(l00 + 1) * Cfg::EP + cc * 8 + k];
-                    const float c = ep[(l00 + tw) * Cfg::EP + cc * 8 + k], d = ep[(l00 + tw + 1) * Cfg::EP + cc * 8 + k];
-                    float m = fmaxf(fmaxf(a, b), fmaxf(c, d)) + bias8[k];
-                    v[k] = (p.epilogue == YOLO_EPI_BIAS_LRELU && m < 0.0f) ? m * p.slope : m;
+                    for (int k = 0; k < 8; ++k) {
+                        const float z[4] = {ep[l00 * Cfg::EP + cc * 8 + k], ep[(l00 + 1) * Cfg::EP + cc * 8 + k], ep[(l00 + tw) * Cfg::EP + cc * 8 + k],
+                                            ep[(l00 + tw + 1) * Cfg::EP + cc * 8 + k]};
+                        float m = 0.0f;
+                        unsigned am = 0;
+#pragma unroll
+                        for (int w4 = 0; w4 < 4; ++w4) {
+                            float t = z[w4] + bias8[k];
+                            t = (p.epilogue == YOLO_EPI_BIAS_LRELU && t < 0.0f) ? t * p.slope : t;
+                            t = __uint_as_float((unsigned)f32_to_bf16(t) << 16);
+                            if (w4 == 0 || t > m) { m = t; am = w4; }
+                        }
+                        v[k] = m;
+                        code |= am << (2 * k);
+                    }
+                    reinterpret_cast<unsigned short *>(const_cast<bf16_t *>(p.aux))[(ob + co) >> 3] = (unsigned short)code;
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        const float a = ep[l00 * Cfg::EP + cc * 8 + k], b = ep[(l00 + 1) * Cfg::EP + cc * 8 + k];
+                        const float c = ep[(l00 + tw) * Cfg::EP + cc * 8 + k], d = ep[(l00 + tw + 1) * Cfg::EP + cc * 8 + k];
+                        float m = fmaxf(fmaxf(a, b), fmaxf(c, d)) + bias8[k];
+                        v[k] = (p.epilogue == YOLO_EPI_BIAS_LRELU && m < 0.0f) ? m * p.slope : m;
+                    }
                 }
                 uint4 pk;
                 pk.x = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
@@ -506,6 +553,38 @@ __global__ void __launch_bounds__(WCO * WPX * 64, 2) igemm_kernel(const IgemmPar
                 }
             }
             continue;
+        }
+        if constexpr (CAN_PREFETCH) {
+            if (aux_fast) {
+#pragma unroll
+                for (int it0 = 0; it0 < NIT; ++it0) {
+                    const uint4 av = axv[it0];
+                    const long ao = axo[it0];
+                    if (ao < 0) continue;
+                    const int lp = tid / CCH + it0 * PX_PER_STEP;
+                    const f32x4 lo = *reinterpret_cast<const f32x4 *>(ep + lp * Cfg::EP + cc * 8);
+                    const f32x4 hi = *reinterpret_cast<const f32x4 *>(ep + lp * Cfg::EP + cc * 8 + 4);
+                    float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                    const unsigned yy[4] = {av.x, av.y, av.z, av.w};
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        const float a = __uint_as_float((k & 1) ? (yy[k >> 1] & 0xffff0000u) : (yy[k >> 1] << 16));
+                        if (p.epilogue == YOLO_EPI_BIAS_ADD_LRELU) {
+                            v[k] += bias8[k] + a;
+                            v[k] = v[k] > 0.0f ? v[k] : v[k] * p.slope;
+                        } else {
+                            v[k] = a > 0.0f ? v[k] : v[k] * p.slope;
+                        }
+                    }
+                    uint4 pk;
+                    pk.x = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
+                    pk.y = (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
+                    pk.z = (unsigned)f32_to_bf16(v[4]) | ((unsigned)f32_to_bf16(v[5]) << 16);
+                    pk.w = (unsigned)f32_to_bf16(v[6]) | ((unsigned)f32_to_bf16(v[7]) << 16);
+                    *reinterpret_cast<uint4 *>(reinterpret_cast<bf16_t *>(p.out) + ao + co) = pk;
+                }
+                continue;
+            }
         }
 #pragma unroll 2
         for (int lp = tid / CCH; lp < ppx_q; lp += PX_PER_STEP) {
@@ -756,8 +835,11 @@ YOLO_API int yolo_igemm(const yolo_igemm_desc *d, const void *in, const void *w,
     p.dbg_it = g_dbg_it;
     if (p.stats && (d->out_fp32 || splits > 1 || d->pool2 || d->px_begin || d->px_end))
         return fail(YOLO_E_UNSUPPORTED, "yolo_igemm: bn_stats needs a plain bf16 launch (no split_k, pool2, pixel range)");
-    p.pool = d->pool2 == 2 ? 2 : (d->pool2 ? 1 : 0);
+    p.pool = (d->pool2 == 2 || d->pool2 == 3) ? d->pool2 : (d->pool2 ? 1 : 0);
     if (p.pool == 2 && !aux) return fail(YOLO_E_ARG, "yolo_igemm: pool2 = 2 writes the un-pooled activation through aux (pointer + aux_* strides)");
+    if (p.pool == 3 && (!aux || (d->Cout & 7) || (d->out_img_stride & 7) || (d->out_row_stride & 7) || (d->out_px_stride & 7) || (d->out_off & 7)))
+        return fail(YOLO_E_ARG, "yolo_igemm: pool2 = 3 writes the arg-max codes through aux (one uint16 per 8 channels at (pooled element address) / 8): "
+                                "Cout and the out_* strides must be multiples of 8");
     p.pool_tw = 16;
     if (p.pool && d->tile_px) return fail(YOLO_E_UNSUPPORTED, "yolo_igemm: tile_px is not available with pool2");
     if (p.pool && (splits > 1 || d->out_fp32 || (d->Ho & 1) || (d->Wo & 1) || (d->epilogue != YOLO_EPI_BIAS && d->epilogue != YOLO_EPI_BIAS_LRELU)))

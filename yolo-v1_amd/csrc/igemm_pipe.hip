@@ -358,12 +358,37 @@ __global__ void __launch_bounds__(TCO * 2, 2) igemm_pipe_kernel(const IgemmParam
                 const long ob = tab[4 * (pbase + l00) + 1];
                 if (ob < 0 || co >= p.Cout) continue;
                 float v[8];
+                if (p.pool == 3) {
+                    // pool2 = 3 (training): besides the pooled map, the window position of every maximum (2 bits per channel, 8
+                    // channels = one ushort) -- all the backward pass needs of the un-pooled activation.  The comparison runs on
+                    // the activations AS STORED (bf16), first maximum in (0,0),(0,1),(1,0),(1,1) order: exactly what
+                    // yolo_maxpool2_bwd_lrelu derives from the un-pooled tensor.
+                    unsigned code = 0;
 #pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    const float a = ep[l00 * EP + cc * 8 + k], b = ep[(l00 + 1) * EP + cc * 8 + k];
-                    const float c = ep[(l00 + wl) * EP + cc * 8 + k], d = ep[(l00 + wl + 1) * EP + cc * 8 + k];
-                    const float m = fmaxf(fmaxf(a, b), fmaxf(c, d)) + bias8[k];
-                    v[k] = (p.epilogue == YOLO_EPI_BIAS_LRELU && m < 0.0f) ? m * p.slope : m;
+                    for (int k = 0; k < 8; ++k) {
+                        const float z[4] = {ep[l00 * EP + cc * 8 + k], ep[(l00 + 1) * EP + cc * 8 + k], ep[(l00 + wl) * EP + cc * 8 + k],
+                                            ep[(l00 + wl + 1) * EP + cc * 8 + k]};
+                        float m = 0.0f;
+                        unsigned am = 0;
+#pragma unroll
+                        for (int w4 = 0; w4 < 4; ++w4) {
+                            float t = z[w4] + bias8[k];
+                            t = (p.epilogue == YOLO_EPI_BIAS_LRELU && t < 0.0f) ? t * p.slope : t;
+                            t = __uint_as_float((unsigned)f32_to_bf16(t) << 16);
+                            if (w4 == 0 || t > m) { m = t; am = w4; }
+                        }
+                        v[k] = m;
+                        code |= am << (2 * k);
+                    }
+                    reinterpret_cast<unsigned short *>(const_cast<bf16_t *>(p.aux))[(ob + co) >> 3] = (unsigned short)code;
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        const float a = ep[l00 * EP + cc * 8 + k], b = ep[(l00 + 1) * EP + cc * 8 + k];
+                        const float c = ep[(l00 + wl) * EP + cc * 8 + k], d = ep[(l00 + wl + 1) * EP + cc * 8 + k];
+                        const float m = fmaxf(fmaxf(a, b), fmaxf(c, d)) + bias8[k];
+                        v[k] = (p.epilogue == YOLO_EPI_BIAS_LRELU && m < 0.0f) ? m * p.slope : m;
+                    }
                 }
                 *reinterpret_cast<uint4 *>(reinterpret_cast<bf16_t *>(p.out) + ob + co) = pack8(v);
             }

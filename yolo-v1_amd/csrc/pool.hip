@@ -121,6 +121,44 @@ __global__ void __launch_bounds__(256) maxpool2_bwd_kernel(const bf16_t *__restr
     *reinterpret_cast<uint4 *>(q + (long)Wp * C + C) = pack8(o[3]);
 }
 
+// the same from the POOLED activation and the arg-max codes a fused conv + pool epilogue left (yolo_igemm pool2 = 3,
+// yolo_conv_stem7_fwd): one uint16 per (pooled pixel, 8 channels), 2 bits per channel = window position of the first maximum
+__global__ void __launch_bounds__(256) maxpool2_bwd_codes_kernel(const bf16_t *__restrict__ ypool, const unsigned short *__restrict__ codes,
+                                                                 const bf16_t *__restrict__ dpool, int N, int H, int W, int C, int hi, int ho, float slope,
+                                                                 bf16_t *__restrict__ dz)
+{
+    const int C8 = C >> 3, Ho = H >> 1, Wo = W >> 1;
+    const long total = (long)N * Ho * Wo * C8;
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int c8 = (int)(idx % C8);
+    const int ox = (int)((idx / C8) % Wo);
+    const int oy = (int)((idx / ((long)C8 * Wo)) % Ho);
+    const int n = (int)(idx / ((long)C8 * Wo * Ho));
+    const int Wp = W + 2 * hi, Hp = H + 2 * hi;
+    const int Wop = Wo + 2 * ho, Hop = Ho + 2 * ho;
+    const long off = (((long)n * Hp + 2 * oy + hi) * Wp + 2 * ox + hi) * C + c8 * 8;
+    const long poff = (((long)n * Hop + oy + ho) * Wop + ox + ho) * C + c8 * 8;
+    float y[8], g[8], o[4][8];
+    unpack8(*reinterpret_cast<const uint4 *>(ypool + poff), y);
+    unpack8(*reinterpret_cast<const uint4 *>(dpool + poff), g);
+    const unsigned code = codes[poff >> 3];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int am = (code >> (2 * k)) & 3;
+        const float gv = g[k] * (y[k] > 0.0f ? 1.0f : slope);
+        o[0][k] = am == 0 ? gv : 0.0f;
+        o[1][k] = am == 1 ? gv : 0.0f;
+        o[2][k] = am == 2 ? gv : 0.0f;
+        o[3][k] = am == 3 ? gv : 0.0f;
+    }
+    bf16_t *q = dz + off;
+    *reinterpret_cast<uint4 *>(q) = pack8(o[0]);
+    *reinterpret_cast<uint4 *>(q + C) = pack8(o[1]);
+    *reinterpret_cast<uint4 *>(q + (long)Wp * C) = pack8(o[2]);
+    *reinterpret_cast<uint4 *>(q + (long)Wp * C + C) = pack8(o[3]);
+}
+
 }  // namespace yolo
 
 using namespace yolo;
@@ -150,6 +188,17 @@ YOLO_API int yolo_maxpool2_bwd_lrelu(const yolo_pool_desc *d, const void *yfull,
     hipLaunchKernelGGL(maxpool2_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, STRM(stream), (const bf16_t *)yfull, (const bf16_t *)dpool,
                        d->N, d->H, d->W, d->C, d->in_halo, d->out_halo, slope, (bf16_t *)dz);
     return check_launch("yolo_maxpool2_bwd_lrelu");
+}
+
+YOLO_API int yolo_maxpool2_bwd_codes(const yolo_pool_desc *d, const void *ypool, const void *codes, const void *dpool, float slope, void *dz,
+                                     yolo_stream_t stream)
+{
+    if (int rc = pool_args(d, "yolo_maxpool2_bwd_codes")) return rc;
+    if (!ypool || !codes || !dpool || !dz) return fail(YOLO_E_ARG, "yolo_maxpool2_bwd_codes: null pointer");
+    const long total = (long)d->N * (d->H / 2) * (d->W / 2) * (d->C / 8);
+    hipLaunchKernelGGL(maxpool2_bwd_codes_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, STRM(stream), (const bf16_t *)ypool,
+                       (const unsigned short *)codes, (const bf16_t *)dpool, d->N, d->H, d->W, d->C, d->in_halo, d->out_halo, slope, (bf16_t *)dz);
+    return check_launch("yolo_maxpool2_bwd_codes");
 }
 
 namespace yolo {

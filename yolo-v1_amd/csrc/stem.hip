@@ -45,6 +45,7 @@ struct StemFwdParams {
     int pool;
     float slope;
     bf16_t *full;           // pool mode only, optional: the un-pooled activation as well (training keeps it for the backward pass)
+    unsigned short *codes;  // pool mode only, optional (pool2 = 3): arg-max codes instead, uint16 per (pooled pixel, 8 channels) at (pooled address) / 8
     long full_img_stride;
     int full_row_stride, full_off;
 };
@@ -151,7 +152,30 @@ __global__ void __launch_bounds__(256, 2) stem_fwd_kernel(const StemFwdParams p)
                                        fmaxf(__uint_as_float(vc[k] & 0xffff0000u), __uint_as_float(vd[k] & 0xffff0000u)));
                 o[k] = (__float_as_uint(lo) >> 16) | (__float_as_uint(hi) & 0xffff0000u);
             }
-            *reinterpret_cast<uint4 *>(ob + (long)(ty * (SF_TH / 2) + qy) * p.out_row_stride + (tx * (SF_TW / 2) + qx) * 64 + c8 * 8) = uint4{o[0], o[1], o[2], o[3]};
+            const long pa = (long)(ty * (SF_TH / 2) + qy) * p.out_row_stride + (tx * (SF_TW / 2) + qx) * 64 + c8 * 8;
+            *reinterpret_cast<uint4 *>(ob + pa) = uint4{o[0], o[1], o[2], o[3]};
+            if (p.codes) {
+                // window position of the first maximum (order (0,0),(0,1),(1,0),(1,1)), 2 bits per channel: with the pooled map, all the
+                // backward pass needs of the un-pooled activation (yolo_wgrad_stem7_pooled codes form)
+                unsigned code = 0;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+#pragma unroll
+                    for (int hf = 0; hf < 2; ++hf) {
+                        const float w0 = hf ? __uint_as_float(va[k] & 0xffff0000u) : __uint_as_float(va[k] << 16);
+                        const float w1 = hf ? __uint_as_float(vb[k] & 0xffff0000u) : __uint_as_float(vb[k] << 16);
+                        const float w2 = hf ? __uint_as_float(vc[k] & 0xffff0000u) : __uint_as_float(vc[k] << 16);
+                        const float w3 = hf ? __uint_as_float(vd[k] & 0xffff0000u) : __uint_as_float(vd[k] << 16);
+                        unsigned am = 0;
+                        float m = w0;
+                        if (w1 > m) { m = w1; am = 1; }
+                        if (w2 > m) { m = w2; am = 2; }
+                        if (w3 > m) { m = w3; am = 3; }
+                        code |= am << (2 * (2 * k + hf));
+                    }
+                }
+                p.codes[((long)n * p.out_img_stride + p.out_off + pa) >> 3] = (unsigned short)code;
+            }
             if (p.full) {
                 bf16_t *fb = p.full + (long)n * p.full_img_stride + p.full_off;
 #pragma unroll
@@ -216,7 +240,8 @@ YOLO_API int yolo_conv_stem7_fwd(const void *x_nhwc4, const void *w_packed, cons
                                  float slope, int pool2, void *out, long out_img_stride, int out_row_stride, int out_off, void *out_full, long full_img_stride,
                                  int full_row_stride, int full_off, yolo_stream_t stream)
 {
-    if (out_full && (!pool2 || (full_row_stride & 7) || (full_img_stride & 7) || (full_off & 7) || ((uintptr_t)out_full & 15)))
+    if (pool2 == 3 && !out_full) return fail(YOLO_E_ARG, "yolo_conv_stem7_fwd: pool2 = 3 writes the arg-max codes through out_full");
+    if (out_full && pool2 != 3 && (!pool2 || (full_row_stride & 7) || (full_img_stride & 7) || (full_off & 7) || ((uintptr_t)out_full & 15)))
         return fail(YOLO_E_ARG, "yolo_conv_stem7_fwd: out_full needs pool2 = 1 and strides in multiples of 8 elements");
     if (!x_nhwc4 || !w_packed || !bias || !out || N <= 0 || Ho <= 0 || Wo <= 0) return fail(YOLO_E_ARG, "yolo_conv_stem7_fwd: bad argument");
     if ((Ho % SF_TH) || (Wo % SF_TW)) return fail(YOLO_E_UNSUPPORTED, "yolo_conv_stem7_fwd: output %dx%d is not a multiple of %dx%d (use yolo_igemm)", Ho, Wo, SF_TH, SF_TW);
@@ -233,7 +258,11 @@ YOLO_API int yolo_conv_stem7_fwd(const void *x_nhwc4, const void *w_packed, cons
     p.x_row_stride = x_row_stride; p.out_row_stride = out_row_stride; p.out_off = out_off;
     p.pool = pool2 ? 1 : 0;
     p.slope = slope;
-    p.full = (bf16_t *)out_full; p.full_img_stride = full_img_stride; p.full_row_stride = full_row_stride; p.full_off = full_off;
+    if (pool2 == 3) {
+        p.codes = (unsigned short *)out_full;
+    } else {
+        p.full = (bf16_t *)out_full; p.full_img_stride = full_img_stride; p.full_row_stride = full_row_stride; p.full_off = full_off;
+    }
     // persistent workgroups, 2 resident per CU (200 VGPRs): 512 .. 2048 measure the same
     const long G = std::min<long>(nt, 1024);
     hipLaunchKernelGGL(stem_fwd_kernel, dim3((unsigned)G), dim3(256), 0, STRM(stream), p);

@@ -775,11 +775,15 @@ struct StemWgradParams {
     long dp_img_stride;
     int dp_row_stride, dp_off;
     float slope;
+    // CODES (MODE 2): `dy` is the POOLED activation (geometry of dpool) and codes the window positions of the maxima that
+    // yolo_conv_stem7_fwd(pool2 = 3) left: uint16 per (pooled pixel, 8 channels) at (pooled element address) / 8
+    const unsigned short *codes;
 };
 
-template <bool POOLED>
+template <int MODE>     // 0: dy is the gradient; 1: rebuilt from the un-pooled activation + dpool; 2: from the pooled activation + codes + dpool
 __global__ void __launch_bounds__(256, 3) stem_wgrad_kernel(const StemWgradParams p)
 {
+    constexpr bool POOLED = MODE != 0;
     __shared__ __attribute__((aligned(16))) char bufA[ST_STAGE];
     __shared__ __attribute__((aligned(16))) char bufB[ST_STAGE];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -817,16 +821,22 @@ __global__ void __launch_bounds__(256, 3) stem_wgrad_kernel(const StemWgradParam
     // vectors and the pooled gradient of the tile fetched one iteration ahead
     const int pw = tid >> 3, pc = tid & 7, pwy = pw >> 3, pwx = pw & 7;
     uint4 ry[4], rg;
+    unsigned rcode = 0;
     auto load_regs = [&](int tile) {
         const int tx = tile % p.tiles_x, r = tile / p.tiles_x;
         const int ty = r % p.tiles_y, n = r / p.tiles_y;
-        const bf16_t *yb = p.dy + (long)n * p.dy_img_stride + (long)(ty * ST_TH + 2 * pwy) * p.dy_row_stride + (tx * ST_TW + 2 * pwx) * 64 + p.dy_off + pc * 8;
-        ry[0] = *reinterpret_cast<const uint4 *>(yb);
-        ry[1] = *reinterpret_cast<const uint4 *>(yb + 64);
-        ry[2] = *reinterpret_cast<const uint4 *>(yb + p.dy_row_stride);
-        ry[3] = *reinterpret_cast<const uint4 *>(yb + p.dy_row_stride + 64);
-        rg = *reinterpret_cast<const uint4 *>(p.dpool + (long)n * p.dp_img_stride + (long)(ty * (ST_TH / 2) + pwy) * p.dp_row_stride + (tx * (ST_TW / 2) + pwx) * 64 +
-                                              p.dp_off + pc * 8);
+        const long pa = (long)n * p.dp_img_stride + (long)(ty * (ST_TH / 2) + pwy) * p.dp_row_stride + (tx * (ST_TW / 2) + pwx) * 64 + p.dp_off + pc * 8;
+        if constexpr (MODE == 2) {
+            ry[0] = *reinterpret_cast<const uint4 *>(p.dy + pa);       // pooled activation: same geometry as dpool
+            rcode = p.codes[pa >> 3];
+        } else {
+            const bf16_t *yb = p.dy + (long)n * p.dy_img_stride + (long)(ty * ST_TH + 2 * pwy) * p.dy_row_stride + (tx * ST_TW + 2 * pwx) * 64 + p.dy_off + pc * 8;
+            ry[0] = *reinterpret_cast<const uint4 *>(yb);
+            ry[1] = *reinterpret_cast<const uint4 *>(yb + 64);
+            ry[2] = *reinterpret_cast<const uint4 *>(yb + p.dy_row_stride);
+            ry[3] = *reinterpret_cast<const uint4 *>(yb + p.dy_row_stride + 64);
+        }
+        rg = *reinterpret_cast<const uint4 *>(p.dpool + pa);
     };
     auto build = [&](char *sb) {
         const unsigned yv[4][4] = {{ry[0].x, ry[0].y, ry[0].z, ry[0].w}, {ry[1].x, ry[1].y, ry[1].z, ry[1].w}, {ry[2].x, ry[2].y, ry[2].z, ry[2].w},
@@ -843,9 +853,13 @@ __global__ void __launch_bounds__(256, 3) stem_wgrad_kernel(const StemWgradParam
                 gg = hf ? __uint_as_float(gv[d] & 0xffff0000u) : __uint_as_float(gv[d] << 16);
                 int am = 0;
                 float m = v[0];
-                if (v[1] > m) { m = v[1]; am = 1; }    // first maximum in (0,0),(0,1),(1,0),(1,1) order, like pool.hip
-                if (v[2] > m) { m = v[2]; am = 2; }
-                if (v[3] > m) { m = v[3]; am = 3; }
+                if constexpr (MODE == 2) {
+                    am = (int)((rcode >> (2 * (2 * d + hf))) & 3u);     // v[0] = the pooled activation = the maximum itself
+                } else {
+                    if (v[1] > m) { m = v[1]; am = 1; }    // first maximum in (0,0),(0,1),(1,0),(1,1) order, like pool.hip
+                    if (v[2] > m) { m = v[2]; am = 2; }
+                    if (v[3] > m) { m = v[3]; am = 3; }
+                }
                 const unsigned bits = (unsigned)f32_to_bf16(gg * (m > 0.0f ? 1.0f : p.slope));
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
@@ -1016,13 +1030,13 @@ using namespace yolo;
 
 static int wgrad_stem7_impl(const void *x_nhwc4, const void *dy, int N, int Ho, int Wo, long x_img_stride, int x_row_stride, long dy_img_stride, int dy_row_stride,
                             int dy_off, const void *dpool, long dp_img_stride, int dp_row_stride, int dp_off, float slope, float *dw_oihw, float *db, float *scratch,
-                            long scratch_elems, yolo_stream_t stream);
+                            long scratch_elems, yolo_stream_t stream, const void *codes);
 
 YOLO_API int yolo_wgrad_stem7(const void *x_nhwc4, const void *dy, int N, int Ho, int Wo, long x_img_stride, int x_row_stride, long dy_img_stride,
                               int dy_row_stride, int dy_off, float *dw_oihw, float *db, float *scratch, long scratch_elems, yolo_stream_t stream)
 {
     return wgrad_stem7_impl(x_nhwc4, dy, N, Ho, Wo, x_img_stride, x_row_stride, dy_img_stride, dy_row_stride, dy_off, nullptr, 0, 0, 0, 1.0f, dw_oihw, db, scratch,
-                            scratch_elems, stream);
+                            scratch_elems, stream, nullptr);
 }
 
 YOLO_API int yolo_wgrad_stem7_pooled(const void *x_nhwc4, const void *y_full, int N, int Ho, int Wo, long x_img_stride, int x_row_stride, long y_img_stride,
@@ -1032,12 +1046,22 @@ YOLO_API int yolo_wgrad_stem7_pooled(const void *x_nhwc4, const void *y_full, in
     if (!dpool || (dp_row_stride & 7) || (dp_img_stride & 7) || (dp_off & 7) || ((uintptr_t)dpool & 15))
         return fail(YOLO_E_ARG, "yolo_wgrad_stem7_pooled: dpool must be a 16-B aligned NHWC buffer with strides in multiples of 8 elements");
     return wgrad_stem7_impl(x_nhwc4, y_full, N, Ho, Wo, x_img_stride, x_row_stride, y_img_stride, y_row_stride, y_off, dpool, dp_img_stride, dp_row_stride, dp_off, slope,
-                            dw_oihw, db, scratch, scratch_elems, stream);
+                            dw_oihw, db, scratch, scratch_elems, stream, nullptr);
+}
+
+YOLO_API int yolo_wgrad_stem7_codes(const void *x_nhwc4, const void *y_pooled, const void *codes, int N, int Ho, int Wo, long x_img_stride, int x_row_stride,
+                                    const void *dpool, long dp_img_stride, int dp_row_stride, int dp_off, float slope, float *dw_oihw, float *db, float *scratch,
+                                    long scratch_elems, yolo_stream_t stream)
+{
+    if (!dpool || !codes || !y_pooled || (dp_row_stride & 7) || (dp_img_stride & 7) || (dp_off & 7) || (((uintptr_t)dpool | (uintptr_t)y_pooled) & 15))
+        return fail(YOLO_E_ARG, "yolo_wgrad_stem7_codes: y_pooled / dpool must be 16-B aligned NHWC buffers of one geometry with strides in multiples of 8 elements");
+    return wgrad_stem7_impl(x_nhwc4, y_pooled, N, Ho, Wo, x_img_stride, x_row_stride, dp_img_stride, dp_row_stride, dp_off, dpool, dp_img_stride, dp_row_stride, dp_off,
+                            slope, dw_oihw, db, scratch, scratch_elems, stream, codes);
 }
 
 static int wgrad_stem7_impl(const void *x_nhwc4, const void *dy, int N, int Ho, int Wo, long x_img_stride, int x_row_stride, long dy_img_stride, int dy_row_stride,
                             int dy_off, const void *dpool, long dp_img_stride, int dp_row_stride, int dp_off, float slope, float *dw_oihw, float *db, float *scratch,
-                            long scratch_elems, yolo_stream_t stream)
+                            long scratch_elems, yolo_stream_t stream, const void *codes)
 {
     if (!x_nhwc4 || !dy || !dw_oihw || !scratch || N <= 0 || Ho <= 0 || Wo <= 0) return fail(YOLO_E_ARG, "yolo_wgrad_stem7: bad argument");
     if ((Ho % ST_TH) || (Wo % ST_TW)) return fail(YOLO_E_UNSUPPORTED, "yolo_wgrad_stem7: output %dx%d is not a multiple of %dx%d (use yolo_im2col_rows + yolo_wgrad)", Ho, Wo, ST_TH, ST_TW);
@@ -1052,11 +1076,13 @@ static int wgrad_stem7_impl(const void *x_nhwc4, const void *dy, int N, int Ho, 
     p.x_img_stride = x_img_stride; p.dy_img_stride = dy_img_stride;
     p.x_row_stride = x_row_stride; p.dy_row_stride = dy_row_stride; p.dy_off = dy_off;
     p.dpool = (const bf16_t *)dpool; p.dp_img_stride = dp_img_stride; p.dp_row_stride = dp_row_stride; p.dp_off = dp_off; p.slope = slope;
+    p.codes = (const unsigned short *)codes;
     long G = std::min<long>(nt, 768);
     G = std::min<long>(G, scratch_elems / ST_PART);
     if (G < 1) return fail(YOLO_E_ARG, "yolo_wgrad_stem7: scratch must hold at least %d floats", ST_PART);
-    if (dpool) hipLaunchKernelGGL(stem_wgrad_kernel<true>, dim3((unsigned)G), dim3(256), 0, STRM(stream), p);
-    else hipLaunchKernelGGL(stem_wgrad_kernel<false>, dim3((unsigned)G), dim3(256), 0, STRM(stream), p);
+    if (dpool && codes) hipLaunchKernelGGL(stem_wgrad_kernel<2>, dim3((unsigned)G), dim3(256), 0, STRM(stream), p);
+    else if (dpool) hipLaunchKernelGGL(stem_wgrad_kernel<1>, dim3((unsigned)G), dim3(256), 0, STRM(stream), p);
+    else hipLaunchKernelGGL(stem_wgrad_kernel<0>, dim3((unsigned)G), dim3(256), 0, STRM(stream), p);
     if (int rc = check_launch("yolo_wgrad_stem7")) return rc;
     hipLaunchKernelGGL(stem_wgrad_reduce_kernel, dim3((ST_PART + 15) / 16), dim3(256), 0, STRM(stream), (const float *)scratch, (int)G, dw_oihw, db);
     return check_launch("yolo_wgrad_stem7(reduce)");

@@ -114,10 +114,13 @@ _SIGS = {
     "yolo_wgrad_stem7": [c_void_p, c_void_p, c_int, c_int, c_int, c_long, c_int, c_long, c_int, c_int, c_void_p, c_void_p, c_void_p, c_long, c_void_p],
     "yolo_wgrad_stem7_pooled": [c_void_p, c_void_p, c_int, c_int, c_int, c_long, c_int, c_long, c_int, c_int, c_void_p, c_long, c_int, c_int, c_float, c_void_p,
                                 c_void_p, c_void_p, c_long, c_void_p],
+    "yolo_wgrad_stem7_codes": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_long, c_int, c_void_p, c_long, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p,
+                               c_long, c_void_p],
     "yolo_maxpool3s2_fwd": [ctypes.POINTER(PoolDesc), c_void_p, c_void_p, c_void_p],
     "yolo_maxpool3s2_bwd": [ctypes.POINTER(PoolDesc), c_void_p, c_void_p, c_void_p, c_int, c_void_p],
     "yolo_maxpool2_fwd": [ctypes.POINTER(PoolDesc), c_void_p, c_void_p, c_void_p],
     "yolo_maxpool2_bwd_lrelu": [ctypes.POINTER(PoolDesc), c_void_p, c_void_p, c_float, c_void_p, c_void_p],
+    "yolo_maxpool2_bwd_codes": [ctypes.POINTER(PoolDesc), c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p],
     "yolo_nchw_f32_to_nhwc_bf16": [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p],
     "yolo_nhwc_bf16_to_nchw_f32": [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p],
     "yolo_nhwc_bf16_to_nchw_bf16": [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p],

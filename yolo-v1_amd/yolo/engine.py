@@ -48,6 +48,7 @@ _SIDE_STREAMS: dict = {}
 SIDE_LOW = True      # ... of the lowest scheduling priority: the dispatcher prefers the data-gradient chain (12.73 -> 12.55 ms per step)
 WGRAD_STREAM = True  # backward: weight gradients run on a second HIP stream beside the data-gradient chain (they are off its critical path)
 WGRAD_PIPE = True  # weight gradient of the big deep 3x3 layers through wgrad_pipe.hip (yolo_wgrad_desc.variant = 5)
+POOL_CODES = True  # training: a fused conv + pool stores the pooled map and 2-bit arg-max codes, not the un-pooled activation
 FUSE_POOL = True   # inference: fold MaxPool2d(2,2) into the preceding conv's epilogue where the geometry allows
 
 
@@ -388,7 +389,8 @@ def igemm_call(d: IgemmDesc, inp, w, bias, aux, out, st, what: str):
 
 
 def _tune_key(d: IgemmDesc):
-    return (d.N, d.Ho, d.Wo, d.KH, d.KW, d.tap_len, d.Cout, d.stride, d.epilogue, d.pool2, d.out_px_stride, d.in_px_stride)
+    # pool2 = 3 (pooled map + arg-max codes, training) runs the launch plan measured for pool2 = 1 (pooled map only, inference)
+    return (d.N, d.Ho, d.Wo, d.KH, d.KW, d.tap_len, d.Cout, d.stride, d.epilogue, 1 if d.pool2 == 3 else d.pool2, d.out_px_stride, d.in_px_stride)
 
 
 load_plans()
@@ -467,7 +469,8 @@ class Plan:
         self._pfb: dict[int, tuple] = {}
         self._pd2: dict[int, tuple] = {}
         self._ws: dict[tuple, list] = {}
-        self.debug_keep = False      # tests: keep the last workspace (activations + gradients) for inspection
+        self.debug_keep = False      # tests: True = keep the last workspace (activations + gradients) for inspection AND store the
+                                     # un-pooled activations; "codes" = keep the workspace of the product path (pooled maps + arg-max codes)
         self.last = None
         # optional persistent gradient arena (data-parallel training): one flat fp32 buffer holding every
         # parameter gradient in the order backward PRODUCES them (last layer first), so that finished
@@ -819,6 +822,11 @@ class Plan:
         fc_saved = {}
         out = None
         skip_pool = False
+        # training, conv -> LeakyReLU -> MaxPool2d(2,2): the fused epilogue stores the pooled map and, per pooled element, the 2-bit
+        # window position of the maximum; the backward pass needs nothing else of the un-pooled activation (debug_keep: the tests'
+        # teacher-forced checks read that activation, so it is written instead)
+        codes_mode = train and POOL_CODES and self.debug_keep is not True      # (debug_keep = "codes": keep the workspace of the product path)
+        ws["codes"] = set()
         for li, L in enumerate(self.layers):
             nxt = ws["acts"][li]
             if L.kind == "conv":
@@ -839,11 +847,17 @@ class Plan:
                     dual = (train and FUSE_POOL and li + 1 < len(self.layers) and self.layers[li + 1].kind == "pool")
                     full = nxt if dual else None
                     dst = ws["acts"][li + 1] if dual else nxt
+                    codes = self._codes(ws, li, dst) if (dual and codes_mode) else None
                     with _timed(f"conv{li}" + ("+pool" if (fuse or dual) else ""), "stem", 2.0 * N * L.Hout * L.Wout * L.Cout * L.Cin * L.K * L.K):
-                        check(L_.yolo_conv_stem7_fwd(cur.p, ptr(wf), ptr(b), N, L.Hout, L.Wout, cur.img_stride, cur.row_stride,
-                                                     self.SLOPE if L.lrelu else 1.0, 1 if (fuse or dual) else 0, dst.p, dst.img_stride, dst.row_stride,
-                                                     dst.interior_off(), full.p if dual else None, full.img_stride if dual else 0,
-                                                     full.row_stride if dual else 0, full.interior_off() if dual else 0, st), "conv_stem7_fwd")
+                        if codes is not None:       # pooled map + arg-max codes: the 411 MB un-pooled activation (batch 64) is never written
+                            check(L_.yolo_conv_stem7_fwd(cur.p, ptr(wf), ptr(b), N, L.Hout, L.Wout, cur.img_stride, cur.row_stride,
+                                                         self.SLOPE if L.lrelu else 1.0, 3, dst.p, dst.img_stride, dst.row_stride,
+                                                         dst.interior_off(), ptr(codes), 0, 0, 0, st), "conv_stem7_fwd")
+                        else:
+                            check(L_.yolo_conv_stem7_fwd(cur.p, ptr(wf), ptr(b), N, L.Hout, L.Wout, cur.img_stride, cur.row_stride,
+                                                         self.SLOPE if L.lrelu else 1.0, 1 if (fuse or dual) else 0, dst.p, dst.img_stride, dst.row_stride,
+                                                         dst.interior_off(), full.p if dual else None, full.img_stride if dual else 0,
+                                                         full.row_stride if dual else 0, full.interior_off() if dual else 0, st), "conv_stem7_fwd")
                     cur = dst
                     skip_pool = fuse or dual
                     continue
@@ -853,10 +867,16 @@ class Plan:
                 if dual:
                     full, pooled = nxt, ws["acts"][li + 1]
                     d = self._conv_desc(L, cur, pooled)
-                    d.pool2 = 2
-                    d.aux_img_stride, d.aux_row_stride, d.aux_px_stride, d.aux_off = full.img_stride, full.row_stride, full.px_stride, full.interior_off()
+                    codes = self._codes(ws, li, pooled) if codes_mode else None
+                    if codes is not None:
+                        d.pool2 = 3
+                        auxp = ptr(codes)
+                    else:
+                        d.pool2 = 2
+                        d.aux_img_stride, d.aux_row_stride, d.aux_px_stride, d.aux_off = full.img_stride, full.row_stride, full.px_stride, full.interior_off()
+                        auxp = full.p
                     with _timed(f"conv{li}+pool", "igemm", 2.0 * N * L.Hout * L.Wout * L.Cout * L.Cin * L.K * L.K):
-                        igemm_call(d, cur.p, ptr(wf), ptr(b), full.p, pooled.p, st, f"igemm conv{li}")
+                        igemm_call(d, cur.p, ptr(wf), ptr(b), auxp, pooled.p, st, f"igemm conv{li}")
                     cur = pooled
                     skip_pool = True
                     continue
@@ -935,6 +955,16 @@ class Plan:
         return out, saved
 
     # ------------------------------------------------------------------ backward
+    @staticmethod
+    def _codes(ws, li: int, pooled: Act) -> torch.Tensor:
+        """arg-max codes of the pool behind conv layer li: uint16 per (pooled pixel, 8 channels), indexed like the pooled map / 8"""
+        c = ws["misc"].get(("codes", li))
+        if c is None:
+            c = torch.empty(pooled.t.numel() // 8, dtype=torch.int16, device=pooled.t.device)
+            ws["misc"][("codes", li)] = c
+        ws["codes"].add(li)
+        return c
+
     def _grad_buf(self, ws, li: int, N, dev) -> Act:
         """gradient wrt the (post-activation-derivative) output of conv layer li, in the geometry
         yolo_wgrad's flat indexing needs (= the layer's INPUT geometry; zero-stuffed for stride 2)."""
@@ -1134,7 +1164,12 @@ class Plan:
                 g = self._grad_buf(ws, lc, N, dev)
                 pd = PoolDesc(N, yfull.H, yfull.W, yfull.C, 1, 1)
                 with _timed(f"pool{li}.bwd", "maxpool2_bwd"):
-                    check(L_.yolo_maxpool2_bwd_lrelu(ctypes.byref(pd), yfull.p, g_act.p, self.SLOPE, g.p, st), "maxpool_bwd")
+                    if lc in ws.get("codes", ()):
+                        ypool = ws["acts"][li]
+                        assert (ypool.Hp, ypool.Wp, ypool.C, ypool.halo) == (g_act.Hp, g_act.Wp, g_act.C, g_act.halo)
+                        check(L_.yolo_maxpool2_bwd_codes(ctypes.byref(pd), ypool.p, ptr(ws["misc"][("codes", lc)]), g_act.p, self.SLOPE, g.p, st), "maxpool_bwd_codes")
+                    else:
+                        check(L_.yolo_maxpool2_bwd_lrelu(ctypes.byref(pd), yfull.p, g_act.p, self.SLOPE, g.p, st), "maxpool_bwd")
                 g_act = g
                 li -= 1
             elif L.kind == "conv":
@@ -1151,7 +1186,13 @@ class Plan:
                             part = torch.empty((768 * 14400,), dtype=torch.float32, device=dev)
                             ws["misc"]["stem_part"] = part
                         with _timed(f"conv{li}.wgrad", "wgrad", 2.0 * N * L.Hout * L.Wout * L.Cout * 147):
-                            if stem_dpool is not None:
+                            if stem_dpool is not None and 0 in ws.get("codes", ()):
+                                yp = ws["acts"][1]
+                                assert (yp.Hp, yp.Wp, yp.C, yp.halo) == (stem_dpool.Hp, stem_dpool.Wp, stem_dpool.C, stem_dpool.halo)
+                                check(L_.yolo_wgrad_stem7_codes(xin.p, yp.p, ptr(ws["misc"][("codes", 0)]), N, L.Hout, L.Wout, xin.img_stride, xin.row_stride,
+                                                                stem_dpool.p, stem_dpool.img_stride, stem_dpool.row_stride, stem_dpool.interior_off(),
+                                                                self.SLOPE if L.lrelu else 1.0, ptr(dw), ptr(db), ptr(part), part.numel(), wst), "wgrad_stem7_codes")
+                            elif stem_dpool is not None:
                                 yf = ws["acts"][0]
                                 check(L_.yolo_wgrad_stem7_pooled(xin.p, yf.p, N, L.Hout, L.Wout, xin.img_stride, xin.row_stride, yf.img_stride, yf.row_stride,
                                                                  yf.interior_off(), stem_dpool.p, stem_dpool.img_stride, stem_dpool.row_stride,
