@@ -59,12 +59,15 @@ struct IgemmCfg {
     static_assert(TPX <= NTHR, "one table entry per thread");
 };
 
-// STATS: the epilogue also accumulates BatchNorm's per-channel sums (yolo_igemm_desc.bn_stats) -- a separate instantiation,
-// so that the kernels of the plain path keep their exact code and register count
-template <int TCO, int TPX, int BK, int WCO, int WPX, int NST, int MF, bool STATS>
-__global__ void __launch_bounds__(WCO * WPX * 64, 2) igemm_kernel(const IgemmParams p)
+// VAR 1 (STATS): the epilogue also accumulates BatchNorm's per-channel sums (yolo_igemm_desc.bn_stats); VAR 2 (CODES): the pooled
+// epilogue also writes the arg-max codes (pool2 = 3).  Separate instantiations, so that the kernels of the plain path keep their
+// exact code and register count: given any more epilogue code the compiler spends up to 256 VGPRs on it and the LDS-light
+// configurations of the HBM-bound layers drop from five co-resident workgroups per CU to two.
+template <int TCO, int TPX, int BK, int WCO, int WPX, int NST, int MF, int VAR>
+__global__ void __launch_bounds__(WCO * WPX * 64, (TCO == 64 && TPX == 128 && BK == 32 && VAR == 0 ? 5 : 2)) igemm_kernel(const IgemmParams p)
 {
     using Cfg = IgemmCfg<TCO, TPX, BK, WCO, WPX, NST, MF>;
+    constexpr bool STATS = VAR == 1, CODES = VAR == 2;
     constexpr bool M16 = MF != MFMA_32x32x16;
     constexpr bool UNEVEN = Cfg::UNEVEN;
     constexpr bool STG = MF == MFMA_16x16x32_STAGGER || UNEVEN;
@@ -167,27 +170,6 @@ __global__ void __launch_bounds__(WCO * WPX * 64, 2) igemm_kernel(const IgemmPar
             b_dst[i] = Cfg::A_BYTES + q * 1024;
         }
     }
-
-    // Epilogues that read a second tensor (residual add / LeakyReLU' gate), bf16 output, small tiles (the HBM-bound thin-K layers):
-    // the aux vectors of a pass are fetched in front of that pass's LDS staging, so that their HBM latency overlaps the staging
-    // and its barriers instead of being paid pixel by pixel inside the store loop (ResNet-50 inference at batch 64: 6.28 -> 5.99 ms;
-    // fetching them already in front of the K loop was slower, 6.16 ms -- they then delay the operand stream).
-    constexpr int E_CCH = TCO / 8, E_PXS = NTHR / E_CCH, E_PPX = Cfg::PPX;
-    constexpr int NIT = (E_PPX + E_PXS - 1) / E_PXS;
-    constexpr bool CAN_PREFETCH = NIT <= 4 && !UNEVEN && !STATS && TCO * TPX <= 128 * 128;   // (the big tiles have no registers to spare)
-    const bool aux_fast = CAN_PREFETCH && (p.epilogue == YOLO_EPI_BIAS_ADD_LRELU || p.epilogue == YOLO_EPI_MUL_DLRELU) && gridDim.y == 1 && !p.pool &&
-                          !p.out_fp32 && co0 + (tid % E_CCH) * 8 + 8 <= p.Cout;
-    uint4 axv[CAN_PREFETCH ? NIT : 1];
-    long axo[CAN_PREFETCH ? NIT : 1];
-    auto aux_fetch = [&](int q) {
-#pragma unroll
-        for (int it = 0; it < NIT; ++it) {
-            const int lp = tid / E_CCH + it * E_PXS;
-            const int px = q * E_PPX + (lp < E_PPX ? lp : 0);
-            axo[it] = lp < E_PPX ? tab[4 * px + 1] : -1;
-            axv[it] = axo[it] >= 0 ? *reinterpret_cast<const uint4 *>(p.aux + tab[4 * px + 2] + co0 + (tid % E_CCH) * 8) : uint4{0u, 0u, 0u, 0u};
-        }
-    };
 
     // ---- K range of this split.  Single-tap problems (Linear layers) interleave the splits: split y
     // takes K steps y, y+S, y+2S, ... so that at any moment the S workgroups of one output tile stream
@@ -442,6 +424,27 @@ __global__ void __launch_bounds__(WCO * WPX * 64, 2) igemm_kernel(const IgemmPar
         for (int k = 0; k < 16; ++k) red[k] = 0.0f;
     }
 
+    // Epilogues that read a second tensor (residual add / LeakyReLU' gate), bf16 output, small tiles (the HBM-bound thin-K layers):
+    // the aux vectors of a pass are fetched in front of that pass's LDS staging, so that their HBM latency overlaps the staging
+    // and its barriers instead of being paid pixel by pixel inside the store loop (ResNet-50 inference at batch 64: 6.28 -> 5.99 ms;
+    // fetching them already in front of the K loop was slower, 6.16 ms -- they then delay the operand stream).
+    constexpr int E_CCH = TCO / 8, E_PXS = NTHR / E_CCH, E_PPX = Cfg::PPX;
+    constexpr int NIT = (E_PPX + E_PXS - 1) / E_PXS;
+    constexpr bool CAN_PREFETCH = NIT <= 4 && !UNEVEN && !STATS && TCO * TPX <= 128 * 128;   // (the big tiles have no registers to spare)
+    const bool aux_fast = CAN_PREFETCH && (p.epilogue == YOLO_EPI_BIAS_ADD_LRELU || p.epilogue == YOLO_EPI_MUL_DLRELU) && gridDim.y == 1 && !p.pool &&
+                          !p.out_fp32 && co0 + (tid % E_CCH) * 8 + 8 <= p.Cout;
+    uint4 axv[CAN_PREFETCH ? NIT : 1];
+    long axo[CAN_PREFETCH ? NIT : 1];
+    auto aux_fetch = [&](int q) {
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int lp = tid / E_CCH + it * E_PXS;
+            const int px = q * E_PPX + (lp < E_PPX ? lp : 0);
+            axo[it] = lp < E_PPX ? tab[4 * px + 1] : -1;
+            axv[it] = axo[it] >= 0 ? *reinterpret_cast<const uint4 *>(p.aux + tab[4 * px + 2] + co0 + (tid % E_CCH) * 8) : uint4{0u, 0u, 0u, 0u};
+        }
+    };
+
     for (int q = 0; q < WPX; ++q) {
         if (q > 0) __syncthreads();   // the previous slab has been streamed out
         if constexpr (CAN_PREFETCH) {
@@ -493,25 +496,25 @@ __global__ void __launch_bounds__(WCO * WPX * 64, 2) igemm_kernel(const IgemmPar
                 const long ob = tab[4 * (pbase + l00) + 1];
                 if (ob < 0 || co >= p.Cout) continue;
                 float v[8];
-                if (p.pool == 3) {
+                if (CODES && p.pool == 3) {
                     // pool2 = 3 (training): the pooled map + the window position of every maximum (2 bits per channel, one ushort
                     // per 8 channels), compared on the activations as stored (bf16), first maximum in (0,0),(0,1),(1,0),(1,1) order
                     unsigned code = 0;
 #pragma unroll
                     for (int k = 0; k < 8; ++k) {
-                        const float z[4] = {ep[l00 * Cfg::EP + cc * 8 + k], ep[(l00 + 1) * Cfg::EP + cc * 8 + k], ep[(l00 + tw) * Cfg::EP + cc * 8 + k],
-                                            ep[(l00 + tw + 1) * Cfg::EP + cc * 8 + k]};
+                        const float *zp = ep + l00 * Cfg::EP + cc * 8 + k;
                         float m = 0.0f;
                         unsigned am = 0;
 #pragma unroll
                         for (int w4 = 0; w4 < 4; ++w4) {
-                            float t = z[w4] + bias8[k];
+                            float t = zp[((w4 >> 1) * tw + (w4 & 1)) * Cfg::EP] + bias8[k];
                             t = (p.epilogue == YOLO_EPI_BIAS_LRELU && t < 0.0f) ? t * p.slope : t;
                             t = __uint_as_float((unsigned)f32_to_bf16(t) << 16);
                             if (w4 == 0 || t > m) { m = t; am = w4; }
                         }
                         v[k] = m;
                         code |= am << (2 * k);
+                        __builtin_amdgcn_sched_barrier(0);     // one channel at a time: the other pixel group's accumulators are still live
                     }
                     reinterpret_cast<unsigned short *>(const_cast<bf16_t *>(p.aux))[(ob + co) >> 3] = (unsigned short)code;
                 } else {
@@ -669,7 +672,7 @@ __global__ void __launch_bounds__(WCO * WPX * 64, 2) igemm_kernel(const IgemmPar
     }
 }
 
-template <int TCO, int TPX, int BK, int WCO, int WPX, int NST, int MF, bool STATS>
+template <int TCO, int TPX, int BK, int WCO, int WPX, int NST, int MF, int VAR>
 static int launch_impl(const IgemmParams &p, int splits, hipStream_t s)
 {
     using Cfg = IgemmCfg<TCO, TPX, BK, WCO, WPX, NST, MF>;
@@ -677,7 +680,7 @@ static int launch_impl(const IgemmParams &p, int splits, hipStream_t s)
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
     if (!attr_done[dev]) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&igemm_kernel<TCO, TPX, BK, WCO, WPX, NST, MF, STATS>), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&igemm_kernel<TCO, TPX, BK, WCO, WPX, NST, MF, VAR>), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
         if (e != hipSuccess) return fail((int)e, "yolo_igemm: hipFuncSetAttribute(%d B LDS): %s", Cfg::LDS_BYTES, hipGetErrorString(e));
         attr_done[dev] = true;
     }
@@ -700,14 +703,14 @@ static int launch_impl(const IgemmParams &p, int splits, hipStream_t s)
     q.nk_per_split = (q.nk + splits - 1) / splits;
     // slabs: every split must store its slab (the finishing pass adds all of them), also one whose K range is empty
     const int real_splits = p.slab_stride ? splits : (q.nk + q.nk_per_split - 1) / q.nk_per_split;
-    hipLaunchKernelGGL((igemm_kernel<TCO, TPX, BK, WCO, WPX, NST, MF, STATS>), dim3(q.n_co_tiles * q.n_px_tiles, real_splits), dim3(Cfg::NTHR), Cfg::LDS_BYTES, s, q);
+    hipLaunchKernelGGL((igemm_kernel<TCO, TPX, BK, WCO, WPX, NST, MF, VAR>), dim3(q.n_co_tiles * q.n_px_tiles, real_splits), dim3(Cfg::NTHR), Cfg::LDS_BYTES, s, q);
     return check_launch("yolo_igemm");
 }
 
 template <int TCO, int TPX, int BK, int WCO, int WPX, int NST, int MF = MFMA_32x32x16>
 static int launch(const IgemmParams &p, int splits, hipStream_t s)
 {
-    return p.stats ? launch_impl<TCO, TPX, BK, WCO, WPX, NST, MF, true>(p, splits, s) : launch_impl<TCO, TPX, BK, WCO, WPX, NST, MF, false>(p, splits, s);
+    return p.stats ? launch_impl<TCO, TPX, BK, WCO, WPX, NST, MF, 1>(p, splits, s) : launch_impl<TCO, TPX, BK, WCO, WPX, NST, MF, 0>(p, splits, s);
 }
 
 // Finishing pass of a split-K conv: acc fp32 [M][Cout] (dense, summed by the split workgroups' atomics) -> the layer's
@@ -844,6 +847,12 @@ YOLO_API int yolo_igemm(const yolo_igemm_desc *d, const void *in, const void *w,
     if (p.pool && d->tile_px) return fail(YOLO_E_UNSUPPORTED, "yolo_igemm: tile_px is not available with pool2");
     if (p.pool && (splits > 1 || d->out_fp32 || (d->Ho & 1) || (d->Wo & 1) || (d->epilogue != YOLO_EPI_BIAS && d->epilogue != YOLO_EPI_BIAS_LRELU)))
         return fail(YOLO_E_UNSUPPORTED, "yolo_igemm: pool2 needs even Ho/Wo, bf16 output, a bias epilogue and no split-K");
+    if (p.pool == 3 && !(force >= 15 && force <= 18)) {
+        // pooled map + arg-max codes: the two 8 x 16-patch configurations in their own instantiations (VAR 2), whatever the hint
+        if (!bk64 || d->w_blocked || p.stats) return fail(YOLO_E_UNSUPPORTED, "yolo_igemm: pool2 = 3 needs tap_len %% 64 == 0 (or tile_hint 16 / 18), plain weights, no bn_stats");
+        if (small_co) return launch_impl<64, 128, 64, 2, 2, 2, MFMA_16x16x32, 2>(p, splits, s);
+        return launch_impl<128, 128, 64, 2, 2, 2, MFMA_16x16x32, 2>(p, splits, s);
+    }
     if (d->w_blocked) {
         if (!bk64) return fail(YOLO_E_UNSUPPORTED, "yolo_igemm: blocked weights need tap_len %% 64 == 0");
         // batch <= 64: a pure weight stream -- three stages keep two 24-KB loads in flight per workgroup (4.9 vs 4.4 TB/s on FC1)

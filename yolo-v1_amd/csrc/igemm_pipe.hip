@@ -54,7 +54,9 @@ struct PipeCfg {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)((const char *)(base) + (unsigned long)(voff)), \
                                      (__attribute__((address_space(3))) void *)(lptr), 16, 0, 0)
 
-template <int TCO, int NTILES, int NST>
+// CODES: the pooled epilogue also writes the arg-max codes (pool2 = 3, 224-pixel tiles only).  A separate instantiation: at
+// 246-254 VGPRs any further epilogue code in the plain kernels makes the register allocator spill around the K loop.
+template <int TCO, int NTILES, int NST, bool CODES = false>
 __global__ void __launch_bounds__(TCO * 2, 2) igemm_pipe_kernel(const IgemmParams p)
 {
     using C = PipeCfg<TCO, NTILES, NST>;
@@ -358,7 +360,7 @@ __global__ void __launch_bounds__(TCO * 2, 2) igemm_pipe_kernel(const IgemmParam
                 const long ob = tab[4 * (pbase + l00) + 1];
                 if (ob < 0 || co >= p.Cout) continue;
                 float v[8];
-                if (p.pool == 3) {
+                if (CODES && p.pool == 3) {
                     // pool2 = 3 (training): besides the pooled map, the window position of every maximum (2 bits per channel, 8
                     // channels = one ushort) -- all the backward pass needs of the un-pooled activation.  The comparison runs on
                     // the activations AS STORED (bf16), first maximum in (0,0),(0,1),(1,0),(1,1) order: exactly what
@@ -366,19 +368,19 @@ __global__ void __launch_bounds__(TCO * 2, 2) igemm_pipe_kernel(const IgemmParam
                     unsigned code = 0;
 #pragma unroll
                     for (int k = 0; k < 8; ++k) {
-                        const float z[4] = {ep[l00 * EP + cc * 8 + k], ep[(l00 + 1) * EP + cc * 8 + k], ep[(l00 + wl) * EP + cc * 8 + k],
-                                            ep[(l00 + wl + 1) * EP + cc * 8 + k]};
+                        const float *zp = ep + l00 * EP + cc * 8 + k;
                         float m = 0.0f;
                         unsigned am = 0;
 #pragma unroll
                         for (int w4 = 0; w4 < 4; ++w4) {
-                            float t = z[w4] + bias8[k];
+                            float t = zp[((w4 >> 1) * wl + (w4 & 1)) * EP] + bias8[k];
                             t = (p.epilogue == YOLO_EPI_BIAS_LRELU && t < 0.0f) ? t * p.slope : t;
                             t = __uint_as_float((unsigned)f32_to_bf16(t) << 16);
                             if (w4 == 0 || t > m) { m = t; am = w4; }
                         }
                         v[k] = m;
                         code |= am << (2 * k);
+                        __builtin_amdgcn_sched_barrier(0);     // one channel at a time: the other pixel group's accumulators are still live
                     }
                     reinterpret_cast<unsigned short *>(const_cast<bf16_t *>(p.aux))[(ob + co) >> 3] = (unsigned short)code;
                 } else {
@@ -523,7 +525,7 @@ __global__ void __launch_bounds__(TCO * 2, 2) igemm_pipe_kernel(const IgemmParam
 #undef PSTAMP
 }
 
-template <int TCO, int NTILES, int NST>
+template <int TCO, int NTILES, int NST, bool CODES = false>
 static int pipe_launch(const IgemmParams &p, int splits, hipStream_t s)
 {
     using C = PipeCfg<TCO, NTILES, NST>;
@@ -531,7 +533,7 @@ static int pipe_launch(const IgemmParams &p, int splits, hipStream_t s)
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
     if (!attr_done[dev]) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&igemm_pipe_kernel<TCO, NTILES, NST>), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&igemm_pipe_kernel<TCO, NTILES, NST, CODES>), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
         if (e != hipSuccess) return fail((int)e, "yolo_igemm: hipFuncSetAttribute(%d B LDS): %s", C::LDS_BYTES, hipGetErrorString(e));
         attr_done[dev] = true;
     }
@@ -544,7 +546,7 @@ static int pipe_launch(const IgemmParams &p, int splits, hipStream_t s)
     if (p.px_fastest < 0) q.px_fastest = 0;
     q.nk_per_split = (q.nk + splits - 1) / splits;
     const int real_splits = p.slab_stride ? splits : 1;
-    hipLaunchKernelGGL((igemm_pipe_kernel<TCO, NTILES, NST>), dim3(q.n_co_tiles * q.n_px_tiles, real_splits), dim3(C::NTHR), C::LDS_BYTES, s, q);
+    hipLaunchKernelGGL((igemm_pipe_kernel<TCO, NTILES, NST, CODES>), dim3(q.n_co_tiles * q.n_px_tiles, real_splits), dim3(C::NTHR), C::LDS_BYTES, s, q);
     return check_launch("yolo_igemm (pipelined)");
 }
 
@@ -568,9 +570,9 @@ int igemm_pipe_launch(const IgemmParams &p, int hint, int splits, hipStream_t s)
     }
     switch (hint) {
     case 15: return pipe_launch<256, 13, 4>(p, splits, s);
-    case 16: return pipe_launch<256, 14, 4>(p, splits, s);
+    case 16: return p.pool == 3 ? pipe_launch<256, 14, 4, true>(p, splits, s) : pipe_launch<256, 14, 4>(p, splits, s);
     case 17: return pipe_launch<128, 13, 3>(p, splits, s);
-    case 18: return pipe_launch<128, 14, 3>(p, splits, s);
+    case 18: return p.pool == 3 ? pipe_launch<128, 14, 3, true>(p, splits, s) : pipe_launch<128, 14, 3>(p, splits, s);
     }
     return fail(YOLO_E_ARG, "yolo_igemm: tile_hint %d is not a pipelined configuration", hint);
 }

@@ -221,8 +221,13 @@ def _run_plan_igemm(L_, d: IgemmDesc, plan, inp, w, bias, aux, out, st, what):
     if d.bn_stats and (plan[0] in ("splitk", "slabs") or (isinstance(plan[0], int) and len(plan) == 4)):
         # a launch that also accumulates BatchNorm statistics must be one plain launch: keep the plan's main configuration
         plan = (plan[1], 1) if plan[0] in ("splitk", "slabs") else (plan[0], plan[1])
-    if d.bn_stats and plan[0] == "tile" and plan[1] in (15, 16, 17, 18):
-        plan = ("tile", 14, plan[2], min(plan[3], 208)) + tuple(plan[4:])   # the pipelined kernels have no statistics epilogue: staggered loop
+    if d.bn_stats:      # the pipelined kernels (15 .. 18) have no statistics epilogue: the staggered 256 x 208 loop takes their place
+        if plan[0] == "tile" and plan[1] in (15, 16, 17, 18):
+            plan = ("tile", 14, plan[2], min(plan[3], 208)) + tuple(plan[4:])
+        elif plan[0] == "skew" and plan[1] in (15, 16, 17, 18):
+            plan = ("skew", 14) + tuple(plan[2:])
+        elif isinstance(plan[0], int) and plan[0] in (15, 16, 17, 18):
+            plan = (14, plan[1])
     d.tile_px, d.px_begin, d.px_end, d.skew_phases, d.skew_step = 0, 0, 0, 0, 0
     if plan[0] in ("splitk", "slabs"):
         # few-pixel deep-K layer: S workgroups per output tile into a dense fp32 scratch (atomics, or one slab per split),
