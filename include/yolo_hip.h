@@ -236,6 +236,10 @@ typedef struct yolo_wgrad_desc {
      * (geo_px_slots = 1) skips the halo slots -- 1.04x .. 1.65x fewer K steps -- and geo_px_slots = 2 with
      * geo_row_slots = 2 * row pitch visits only the non-zero slots of a stride-2 conv's zero-stuffed gradient (4x fewer). */
     int32_t geo_W, geo_H, geo_img_slots, geo_row_slots, geo_px_slots, geo_slot0;
+    double *dw_sumsq;                /* optional (device double, NULL = off): += sum of squares of the dw this launch stores -- the
+                                        global gradient norm of clip_grad_norm_ (trainer.py:79) then needs no pass over the 822 MB
+                                        gradient of the Linear behind nn.Flatten.  Only with every tile stored by one workgroup
+                                        (split = 1, accumulate = 0, variant 0 / 1, Cin % 4 == 0); otherwise YOLO_E_UNSUPPORTED */
 } yolo_wgrad_desc;
 
 int yolo_wgrad(const yolo_wgrad_desc *d, const void *x_bf16, const void *dy_bf16,

@@ -547,3 +547,30 @@ def test_gradient_arena_equals_autograd_path(model):
     for (n, p1), (_, p2) in zip(m1.named_parameters(), m2.named_parameters()):
         assert p2.grad.data_ptr() >= arena.data_ptr() and p2.grad.data_ptr() < arena.data_ptr() + arena.numel() * 4, n
         assert _rel(p2.grad, p1.grad) < 0.03, (n, _rel(p2.grad, p1.grad))
+
+
+def test_adam_takes_the_big_linear_gradient_norm_from_the_weight_gradient_kernel():
+    """Plan.backward leaves |dW|_F^2 of the Linear behind nn.Flatten, summed by yolo_wgrad while it stores dW (yolo_wgrad_desc.dw_sumsq,
+    engine.FC_NORM_IN_WGRAD); the optimizer uses it instead of reading the 822 MB gradient -- only while .grad is still the memory
+    that backward pass wrote, unmodified."""
+    from yolo import YOLOLoss, YOLOv1, engine
+    from yolo.optim import Adam, grad_norm_sq
+    torch.manual_seed(0)
+    m = YOLOv1().cuda().eval()
+    x = torch.from_numpy(synth.synth_images(2, 3)).cuda()
+    t = torch.from_numpy(synth.synth_targets(2, 4)).cuda()
+    opt = Adam(m.parameters(), lr=1e-4, max_grad_norm=10.0)
+    plan = m.hip_plan()
+    opt.attach_plan(plan)
+    loss, _ = YOLOLoss()(m(x), t)
+    loss.backward()
+    params = [p for p in m.parameters() if p.grad is not None]
+    big = max(params, key=lambda p: p.numel())
+    assert id(big) in plan.grad_norm_sq and plan.grad_norm_sq[id(big)][0] == (big.grad.data_ptr(), tuple(big.grad.shape)), "autograd must take the gradient over without a copy"
+    full = grad_norm_sq(params).item()
+    hinted = grad_norm_sq(params, plan.grad_norm_sq).item()
+    direct = big.grad.double().pow(2).sum().item()
+    assert abs(plan.grad_norm_sq[id(big)][2].item() - direct) <= 1e-5 * direct
+    assert abs(full - hinted) <= 1e-5 * full
+    big.grad.mul_(2.0)                                   # modified in place: the stored norm no longer describes it
+    assert abs(grad_norm_sq(params, plan.grad_norm_sq).item() - grad_norm_sq(params).item()) <= 1e-9 * full

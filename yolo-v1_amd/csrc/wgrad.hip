@@ -243,6 +243,7 @@ __global__ void __launch_bounds__(256, 2) wgrad_kernel(const WgradParams p)
     const long ldw = (long)p.ntaps * p.Cin;
     float *ot = reinterpret_cast<float *>(bufA);
     const bool vec_ok = !atomic && (p.Cin & 3) == 0 && ((uintptr_t)p.dw & 15) == 0;
+    float ssq = 0.0f;      // p.sumsq: squares of the values this thread stores (the host requires the vector store path for it)
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
         __syncthreads();   // (first pass: every wave is done reading the stage buffers)
@@ -261,8 +262,11 @@ __global__ void __launch_bounds__(256, 2) wgrad_kernel(const WgradParams p)
             for (int it = 0; it < 8; ++it) {
                 const int idx = it * 256 + tid, row = idx >> 5, c4 = (idx & 31) * 4;
                 const int co = co0 + h * 64 + row, ci = ci0 + c4;
-                if (co < p.Cout && c4 < col_lim)   // Cin % 4 == 0: a quad is inside or outside as a whole
-                    *reinterpret_cast<float4 *>(p.dw + (long)co * ldw + (long)tap * p.Cin + ci) = *reinterpret_cast<const float4 *>(ot + row * WG_T + c4);
+                if (co < p.Cout && c4 < col_lim) {   // Cin % 4 == 0: a quad is inside or outside as a whole
+                    const float4 v = *reinterpret_cast<const float4 *>(ot + row * WG_T + c4);
+                    *reinterpret_cast<float4 *>(p.dw + (long)co * ldw + (long)tap * p.Cin + ci) = v;
+                    ssq += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+                }
             }
         } else {
 #pragma unroll 4
@@ -277,6 +281,15 @@ __global__ void __launch_bounds__(256, 2) wgrad_kernel(const WgradParams p)
                 }
             }
         }
+    }
+    if (p.sumsq) {       // wave-uniform branch; one fp64 atomic per workgroup
+        double s = (double)ssq;
+        for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+        __syncthreads();
+        double *part = reinterpret_cast<double *>(bufA);
+        if (lane == 0) part[wave] = s;
+        __syncthreads();
+        if (tid == 0) atomicAdd(p.sumsq, part[0] + part[1] + part[2] + part[3]);
     }
 }
 
@@ -1181,6 +1194,8 @@ YOLO_API int yolo_wgrad(const yolo_wgrad_desc *d, const void *x, const void *dy,
             const long nblk = (long)p.main_tiles * bs + (long)p.tail_tiles * p.tail_split;
             grid = dim3((unsigned)((nblk + slots - 1) / slots * slots));   // whole groups of `slots` ids for the XCD map
         }
+        if (d->dw_sumsq && (pipe || big || d->variant == 4 || p.atomic || (d->Cin & 3) || ((uintptr_t)dw & 15)))
+            return fail(YOLO_E_UNSUPPORTED, "yolo_wgrad: dw_sumsq needs the 128 x 128 kernel storing every tile from one workgroup (split 1, no accumulate, Cin %% 4 == 0)");
         if (pipe) {
             if (int rc = wgrad_pipe_launch(p, grid, s)) return rc;
         } else if (big) {
@@ -1196,6 +1211,7 @@ YOLO_API int yolo_wgrad(const yolo_wgrad_desc *d, const void *x, const void *dy,
         } else if (d->variant == 4) {
             hipLaunchKernelGGL(wgrad8_kernel, grid, dim3(512), 0, s, p);
         } else {
+            p.sumsq = d->dw_sumsq;
             hipLaunchKernelGGL(wgrad_kernel, grid, dim3(256), 0, s, p);
         }
         if (int rc = check_launch("yolo_wgrad")) return rc;

@@ -18,6 +18,7 @@ struct WgradParams {
     const bf16_t *dy;
     float *dw;
     float *db;              // optional: bias gradient, accumulated by the (tap 0, ci-tile 0) workgroups
+    double *sumsq;          // optional (128 x 128 kernel, tiles stored by ONE workgroup): += sum of squares of the dw this launch writes
     long P;                 // pixels to reduce over
     // pixel p -> slot in the dy / x buffers.  gW == 0: p is the slot ("flat" indexing).  Else p = (n*gH + oy)*gW + ox and
     // slot = n*g_img + oy*g_row + ox*g_px + g_off (interior pixels of a zero-haloed buffer, optionally every 2nd one);

@@ -58,6 +58,7 @@ class WgradDesc(ctypes.Structure):
         ("split", ctypes.c_int32), ("accumulate", ctypes.c_int32), ("variant", ctypes.c_int32),
         ("geo_W", ctypes.c_int32), ("geo_H", ctypes.c_int32), ("geo_img_slots", ctypes.c_int32), ("geo_row_slots", ctypes.c_int32),
         ("geo_px_slots", ctypes.c_int32), ("geo_slot0", ctypes.c_int32),
+        ("dw_sumsq", ctypes.c_void_p),
     ]
 
 

@@ -48,6 +48,7 @@ _SIDE_STREAMS: dict = {}
 SIDE_LOW = True      # ... of the lowest scheduling priority: the dispatcher prefers the data-gradient chain (12.73 -> 12.55 ms per step)
 WGRAD_STREAM = True  # backward: weight gradients run on a second HIP stream beside the data-gradient chain (they are off its critical path)
 WGRAD_PIPE = True  # weight gradient of the big deep 3x3 layers through wgrad_pipe.hip (yolo_wgrad_desc.variant = 5)
+FC_NORM_IN_WGRAD = 1 << 26   # Linear layers with at least this many weights: yolo_wgrad also sums the squares of the gradient it stores
 POOL_CODES = True  # training: a fused conv + pool stores the pooled map and 2-bit arg-max codes, not the un-pooled activation
 FUSE_POOL = True   # inference: fold MaxPool2d(2,2) into the preceding conv's epilogue where the geometry allows
 
@@ -474,6 +475,7 @@ class Plan:
         self._pfb: dict[int, tuple] = {}
         self._pd2: dict[int, tuple] = {}
         self._ws: dict[tuple, list] = {}
+        self.grad_norm_sq: dict = {}   # id(weight) -> ((data_ptr, shape) of the gradient, its version, device double |g|^2) left by the last backward pass
         self.debug_keep = False      # tests: True = keep the last workspace (activations + gradients) for inspection AND store the
                                      # un-pooled activations; "codes" = keep the workspace of the product path (pooled maps + arg-max codes)
         self.last = None
@@ -830,6 +832,7 @@ class Plan:
         # training, conv -> LeakyReLU -> MaxPool2d(2,2): the fused epilogue stores the pooled map and, per pooled element, the 2-bit
         # window position of the maximum; the backward pass needs nothing else of the un-pooled activation (debug_keep: the tests'
         # teacher-forced checks read that activation, so it is written instead)
+        self.grad_norm_sq.clear()
         codes_mode = train and POOL_CODES and self.debug_keep is not True      # (debug_keep = "codes": keep the workspace of the product path)
         ws["codes"] = set()
         for li, L in enumerate(self.layers):
@@ -1102,8 +1105,17 @@ class Plan:
                 # weight / bias gradient, native [O][K] layout
                 dw, db = grad_tensors(li)
                 wd = WgradDesc(N, ldg, L.Cin, L.Cout, L.Cin, 1, 1, 0, 0, 1, 0)
+                nsq = None
+                if L.Cout * L.Cin >= FC_NORM_IN_WGRAD and L.Cin % 4 == 0:
+                    # the kernel that stores this gradient also sums its squares: the optimizer's global-norm pass (clip_grad_norm_) then
+                    # need not read the 822 MB of the Linear behind nn.Flatten again (yolo.optim.grad_norm_sq, `known`)
+                    nsq = torch.zeros((), dtype=torch.float64, device=dev)
+                    wd.dw_sumsq = nsq.data_ptr()
                 with _timed(f"fc{li}.wgrad", "wgrad", 2.0 * N * L.Cout * L.Cin):
                     check(L_.yolo_wgrad(ctypes.byref(wd), ptr(xin), ptr(gb), ptr(dw), ptr(db), st), f"wgrad fc{li}")
+                if nsq is not None:
+                    # (no reference to dw itself: autograd takes the gradient over without a copy only while nobody else holds it)
+                    self.grad_norm_sq[id(L.weight)] = ((dw.data_ptr(), tuple(dw.shape)), dw._version, nsq)
                 grads[li] = (dw, db)
                 self._layer_done(li)
                 # data gradient

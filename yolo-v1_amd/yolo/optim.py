@@ -22,16 +22,34 @@ def _f32c(g: torch.Tensor) -> torch.Tensor:
     return g if (g.dtype == torch.float32 and g.is_contiguous()) else g.float().contiguous()
 
 
-def grad_norm_sq(params) -> torch.Tensor:
+def grad_norm_sq(params, known=None) -> torch.Tensor:
     """device double holding sum over all gradients of g^2 (enqueued, not synchronised): one launch
-    for the whole list (yolo_sumsq_f32_multi)."""
-    grads = [_f32c(p.grad) for p in params if p.grad is not None]
+    for the whole list (yolo_sumsq_f32_multi).
+
+    ``known``: {id(param): ((data_ptr, shape) of the gradient, its version counter, device double)} -- squared norms the producer of a gradient
+    already has (engine.Plan.backward: yolo_wgrad sums the squares of the 205 M-element gradient of the Linear behind
+    nn.Flatten while it stores it, yolo_wgrad_desc.dw_sumsq: 822 MB less to read).  An entry is used only while the parameter's
+    .grad is still that very memory, unmodified (autograd hands over a detached alias that shares the version counter; accumulation,
+    an all-reduce or clipping in place bump it)."""
+    grads, extra = [], []
+    for p in params:
+        if p.grad is None:
+            continue
+        k = known.get(id(p)) if known else None
+        if k is not None and k[0] == (p.grad.data_ptr(), tuple(p.grad.shape)) and k[1] == p.grad._version:
+            extra.append(k[2])
+        else:
+            grads.append(_f32c(p.grad))
+    dev = (grads[0] if grads else extra[0]).device
     _hip.require_cuda(*grads)
-    with torch.cuda.device(grads[0].device):
-        acc = torch.zeros((), dtype=torch.float64, device=grads[0].device)
-        gp = (ctypes.c_void_p * len(grads))(*[g.data_ptr() for g in grads])
-        gn = (ctypes.c_long * len(grads))(*[g.numel() for g in grads])
-        check(lib().yolo_sumsq_f32_multi(gp, gn, len(grads), ptr(acc), stream()), "yolo_sumsq_f32_multi")
+    with torch.cuda.device(dev):
+        acc = torch.zeros((), dtype=torch.float64, device=dev)
+        if grads:
+            gp = (ctypes.c_void_p * len(grads))(*[g.data_ptr() for g in grads])
+            gn = (ctypes.c_long * len(grads))(*[g.numel() for g in grads])
+            check(lib().yolo_sumsq_f32_multi(gp, gn, len(grads), ptr(acc), stream()), "yolo_sumsq_f32_multi")
+        for e in extra:
+            acc += e
     return acc
 
 
@@ -57,6 +75,7 @@ class Adam(torch.optim.Optimizer):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
         self.max_grad_norm = max_grad_norm
         self.bf16_shadow: dict[int, tuple] = {}   # id(param) -> (bf16 tensor refreshed in the same pass, callback(param) | None)
+        self.plans: list = []                     # attached engine plans: their backward passes leave squared gradient norms (grad_norm_sq)
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -72,7 +91,11 @@ class Adam(torch.optim.Optimizer):
             return self._step_on_device(all_params, loss)
 
     def _step_on_device(self, all_params, loss):
-        norm = grad_norm_sq(all_params) if self.max_grad_norm is not None else None
+        known = {}
+        for plan in self.plans:
+            known.update(plan.grad_norm_sq)
+            plan.grad_norm_sq.clear()          # one backward pass, one use
+        norm = grad_norm_sq(all_params, known) if self.max_grad_norm is not None else None
         st = stream()
         for group in self.param_groups:
             b1, b2 = group["betas"]
@@ -114,3 +137,5 @@ class Adam(torch.optim.Optimizer):
         pass that updates their fp32 masters (``plan``: ``model.hip_plan()``)."""
         for p, shadow, fresh in plan.bf16_shadows():
             self.bf16_shadow[id(p)] = (shadow, fresh)
+        if all(pl is not plan for pl in self.plans):
+            self.plans.append(plan)
