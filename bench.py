@@ -225,7 +225,7 @@ def main():
         opt = Adam(model.parameters(), lr=1e-4, weight_decay=5e-4, max_grad_norm=10.0)  # clip_grad_norm_(10) + Adam fused
         opt.attach_plan(model.hip_plan())   # Adam also refreshes the bf16 operands of the Linear layers
         # data parallel: gradient arena + all-reduce overlapped with the backward pass (FC1's 822 MB first)
-        ar = make_grad_reducer(model, dev) if use_dist else None      # the reducer the shipped training loop uses
+        ar = make_grad_reducer(model, dev) if (use_dist and world > 1) else None      # the reducer the shipped training loop uses (nothing to reduce in a world of one)
 
         def step():
             opt.zero_grad(set_to_none=True)
@@ -250,7 +250,7 @@ def main():
                  "steps": ksteps, "global_batch": world * B,
                  "step_tflops": round(120.8e9 * world * B / (dt_t / ksteps) / 1e12, 1),
                  "roofline": troof.get("wgrad"), "roofline_igemm": troof.get("igemm"),
-                 "includes": "zero_grad, forward, YOLOLoss fwd+bwd (HIP), backward (HIP), " + ("RCCL grad all-reduce overlapped with backward, " if use_dist else "") + "clip_grad_norm_(10), Adam(lr 1e-4, wd 5e-4)",
+                 "includes": "zero_grad, forward, YOLOLoss fwd+bwd (HIP), backward (HIP), " + ("RCCL grad all-reduce overlapped with backward, " if ar is not None else "") + "clip_grad_norm_(10), Adam(lr 1e-4, wd 5e-4)",
                  "flops_per_image": 120.8e9, "first_layer_dgrad": "skipped (input needs no gradient)"}
         model.eval()
 
