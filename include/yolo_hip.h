@@ -240,8 +240,15 @@ typedef struct yolo_wgrad_desc {
                                         global gradient norm of clip_grad_norm_ (trainer.py:79) then needs no pass over the 822 MB
                                         gradient of the Linear behind nn.Flatten.  Only with every tile stored by one workgroup
                                         (split = 1, accumulate = 0, variant 0 / 1, Cin % 4 == 0); otherwise YOLO_E_UNSUPPORTED */
+    float *slabs;                    /* optional (variant 5, accumulate = 0, Cin % 4 == 0): scratch of slab_floats floats.  Every workgroup then
+                                        STORES its 256 x 256 partial tile there and a second kernel adds the partials of a tile in pixel-range
+                                        order into dw -- no fp32 atomics on dw (1.5 TB/s chip-wide, 60-90 k cycles per workgroup), dw need not
+                                        be zero-filled, and dw is bit-reproducible.  yolo_wgrad_slab_floats gives the size a launch needs */
+    int64_t slab_floats;
 } yolo_wgrad_desc;
 
+/* floats of yolo_wgrad_desc.slabs the launch described by d would use (0: the variant has no slab mode); launches nothing */
+int yolo_wgrad_slab_floats(const yolo_wgrad_desc *d, long *floats);
 int yolo_wgrad(const yolo_wgrad_desc *d, const void *x_bf16, const void *dy_bf16,
                float *dw_packed, float *db, yolo_stream_t stream);
 

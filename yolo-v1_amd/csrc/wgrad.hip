@@ -99,7 +99,8 @@ __global__ void __launch_bounds__(256, 2) wgrad_kernel(const WgradParams p)
     int bid;
     long pbeg, pend;
     bool atomic;
-    wgrad_map(p, nwg, bid, pbeg, pend, atomic);
+    int part_unused;
+    wgrad_map(p, nwg, bid, pbeg, pend, atomic, part_unused);
     if (pbeg >= pend) return;   // empty range of a rounded-up split (the whole workgroup leaves)
     // co-tile fastest, then ci-tile, then tap: neighbours share the x tile of one tap
     const int co_tile = bid % p.n_co_tiles;
@@ -342,7 +343,8 @@ __global__ void __launch_bounds__(512, 2) wgrad8_kernel(const WgradParams p)
     int bid;
     long pbeg, pend;
     bool atomic;
-    wgrad_map(p, nwg, bid, pbeg, pend, atomic);
+    int part_unused;
+    wgrad_map(p, nwg, bid, pbeg, pend, atomic, part_unused);
     if (pbeg >= pend) return;   // empty range of a rounded-up split (the whole workgroup leaves)
     // co-tile fastest, then ci-tile, then tap: neighbours share the x tile of one tap
     const int co_tile = bid % p.n_co_tiles;
@@ -546,7 +548,8 @@ __global__ void __launch_bounds__(512, 1) wgrad256_kernel(const WgradParams p)
     int bid;
     long pbeg, pend;
     bool atomic;
-    wgrad_map(p, nwg, bid, pbeg, pend, atomic);
+    int part_unused;
+    wgrad_map(p, nwg, bid, pbeg, pend, atomic, part_unused);
     if (pbeg >= pend) return;   // empty range of a rounded-up split (the whole workgroup leaves)
     const int co_tile = bid % p.n_co_tiles;
     const int rest = bid / p.n_co_tiles;
@@ -1101,7 +1104,22 @@ static int wgrad_stem7_impl(const void *x_nhwc4, const void *dy, int N, int Ho, 
     return check_launch("yolo_wgrad_stem7(reduce)");
 }
 
+static int wgrad_run(const yolo_wgrad_desc *d, const void *x, const void *dy, float *dw, float *db, yolo_stream_t stream, long *query);
+
 YOLO_API int yolo_wgrad(const yolo_wgrad_desc *d, const void *x, const void *dy, float *dw, float *db, yolo_stream_t stream)
+{
+    return wgrad_run(d, x, dy, dw, db, stream, nullptr);
+}
+
+YOLO_API int yolo_wgrad_slab_floats(const yolo_wgrad_desc *d, long *floats)
+{
+    if (!floats) return fail(YOLO_E_ARG, "yolo_wgrad_slab_floats: null pointer");
+    *floats = 0;
+    static float dummy[4];      // the schedule does not depend on the operand addresses; nothing is launched
+    return wgrad_run(d, dummy, dummy, dummy, nullptr, nullptr, floats);
+}
+
+static int wgrad_run(const yolo_wgrad_desc *d, const void *x, const void *dy, float *dw, float *db, yolo_stream_t stream, long *query)
 {
     if (!d || !x || !dy || (!dw && !db)) return fail(YOLO_E_ARG, "yolo_wgrad: null pointer");
     if (d->P <= 0 || d->Cout <= 0 || d->Cin <= 0 || d->KH <= 0 || d->KW <= 0 || d->split < 0) return fail(YOLO_E_ARG, "yolo_wgrad: bad descriptor");
@@ -1194,10 +1212,39 @@ YOLO_API int yolo_wgrad(const yolo_wgrad_desc *d, const void *x, const void *dy,
             const long nblk = (long)p.main_tiles * bs + (long)p.tail_tiles * p.tail_split;
             grid = dim3((unsigned)((nblk + slots - 1) / slots * slots));   // whole groups of `slots` ids for the XCD map
         }
+        // slab mode (variant 5): partial tiles as plain stores + a fixed-order sum instead of fp32 atomics
+        int main_ranges = 1, tail_ranges = 1;
+        if (d->slabs || query) {
+            long need = 0;
+            if (pipe) {
+                long nparts;
+                if (d->split > 0) {
+                    nparts = (long)tiles * grid.y;
+                    main_ranges = (int)grid.y;
+                } else {
+                    nparts = (long)p.main_tiles * p.main_split + (long)p.tail_tiles * p.tail_split;
+                    main_ranges = (int)std::min<long>(p.main_split, (d->P + p.per_main - 1) / p.per_main);
+                    tail_ranges = (int)std::min<long>(p.tail_split, (d->P + p.per_tail - 1) / p.per_tail);
+                }
+                need = nparts * 256 * 256;
+            }
+            if (query) {
+                *query = need;
+                return 0;
+            }
+            if (!pipe || d->accumulate || (d->Cin & 3) || (((uintptr_t)dw | (uintptr_t)d->slabs) & 15))
+                return fail(YOLO_E_UNSUPPORTED, "yolo_wgrad: slabs need variant 5, accumulate = 0, Cin %% 4 == 0 and 16-B aligned dw / slabs");
+            if (d->slab_floats < need) return fail(YOLO_E_ARG, "yolo_wgrad: slabs hold %ld floats, this launch needs %ld (yolo_wgrad_slab_floats)", (long)d->slab_floats, need);
+            p.slabs = d->slabs;
+            p.atomic = 0;
+        }
         if (d->dw_sumsq && (pipe || big || d->variant == 4 || p.atomic || (d->Cin & 3) || ((uintptr_t)dw & 15)))
             return fail(YOLO_E_UNSUPPORTED, "yolo_wgrad: dw_sumsq needs the 128 x 128 kernel storing every tile from one workgroup (split 1, no accumulate, Cin %% 4 == 0)");
         if (pipe) {
             if (int rc = wgrad_pipe_launch(p, grid, s)) return rc;
+            if (p.slabs) {
+                if (int rc = wgrad_slab_sum_launch(p, tiles, main_ranges, tail_ranges, s)) return rc;
+            }
         } else if (big) {
             static bool lds_ok = false;
             if (!lds_ok) {

@@ -19,6 +19,8 @@ struct WgradParams {
     float *dw;
     float *db;              // optional: bias gradient, accumulated by the (tap 0, ci-tile 0) workgroups
     double *sumsq;          // optional (128 x 128 kernel, tiles stored by ONE workgroup): += sum of squares of the dw this launch writes
+    float *slabs;           // optional (wgrad_pipe.hip): every workgroup STORES its 256 x 256 partial tile at slabs + part * 65536 (part = its
+                            // (tile, pixel range) number, see wgrad_map) instead of adding it to dw; wgrad_slab_sum_kernel adds them up in range order
     long P;                 // pixels to reduce over
     // pixel p -> slot in the dy / x buffers.  gW == 0: p is the slot ("flat" indexing).  Else p = (n*gH + oy)*gW + ox and
     // slot = n*g_img + oy*g_row + ox*g_px + g_off (interior pixels of a zero-haloed buffer, optionally every 2nd one);
@@ -51,9 +53,10 @@ constexpr int WG_SLOTS = 512;   // 256 CUs x 2 resident workgroups (64 KB of LDS
 // workgroup -> (logical tile id, first pixel, pixels).  Hardware hands consecutive workgroup ids to the 8 XCDs round-robin;
 // within every group of 512 ids an XCD gets 64 CONSECUTIVE logical workgroups: same pixel range, neighbouring tiles
 // (co fastest), so the dy / x rows they stream are shared through that XCD's L2.
-__device__ __forceinline__ void wgrad_map(const WgradParams &p, int nwg, int &bid, long &pbeg, long &pend, bool &atomic)
+__device__ __forceinline__ void wgrad_map(const WgradParams &p, int nwg, int &bid, long &pbeg, long &pend, bool &atomic, int &part)
 {
     atomic = p.atomic & 1;
+    part = 0;
     if (p.seg) {
         const int id = blockIdx.x, per_xcd = p.slots >> 3;
         const int L = id / p.slots * p.slots + (id & 7) * per_xcd + ((id % p.slots) >> 3);
@@ -66,12 +69,14 @@ __device__ __forceinline__ void wgrad_map(const WgradParams &p, int nwg, int &bi
             range = within / tpr;
             bid = round * tpr + within % tpr;
             per = p.per_main;
+            part = bid * p.main_split + range;
         } else {
             const int t = L - nmain, tt = max(p.tail_tiles, 1);
             range = p.tail_tiles > 0 ? t / tt : p.tail_split;   // no tail: past every range -> empty
             bid = p.main_tiles + t % tt;
             per = p.per_tail;
             atomic = (p.atomic >> 1) & 1;
+            part = nmain + (t % tt) * p.tail_split + range;
         }
         pbeg = (long)range * per;
         pend = min(p.P, pbeg + per);
@@ -81,6 +86,7 @@ __device__ __forceinline__ void wgrad_map(const WgradParams &p, int nwg, int &bi
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
         pbeg = (long)blockIdx.y * p.p_per_split;
         pend = min(p.P, pbeg + p.p_per_split);
+        part = bid * (int)gridDim.y + (int)blockIdx.y;
     }
 }
 
@@ -89,6 +95,8 @@ __device__ __forceinline__ void wgrad_map(const WgradParams &p, int nwg, int &bi
 
 // wgrad_pipe.hip: 256 x 256 tile, wave tile 128 x 64, register-pipelined one-barrier loop (yolo_wgrad_desc.variant = 5)
 int wgrad_pipe_launch(const WgradParams &p, dim3 grid, hipStream_t s);
+// ... slab mode: sum of the partial tiles into the packed gradient (main_ranges / tail_ranges = pixel ranges that hold pixels)
+int wgrad_slab_sum_launch(const WgradParams &p, int tiles, int main_ranges, int tail_ranges, hipStream_t s);
 // igemm.hip: the debug buffer of yolo_debug_stamps (diagnostic builds)
 void debug_stamp_target(long **buf, int *it);
 

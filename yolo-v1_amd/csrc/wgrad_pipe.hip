@@ -66,8 +66,9 @@ __global__ void __launch_bounds__(wp::NTHR, 2) wgrad_pipe_kernel(const WgradPara
     int bid;
     long pbeg, pend;
     bool atomic;
-    wgrad_map(p, nwg, bid, pbeg, pend, atomic);
-    if (pbeg >= pend) return;
+    int part;
+    wgrad_map(p, nwg, bid, pbeg, pend, atomic, part);
+    if (pbeg >= pend) return;      // (slab mode: the host sums only the ranges that hold pixels)
     const int co_tile = bid % p.n_co_tiles;
     const int rest = bid / p.n_co_tiles;
     const int ci_tile = rest % p.n_ci_tiles;
@@ -371,6 +372,37 @@ __global__ void __launch_bounds__(wp::NTHR, 2) wgrad_pipe_kernel(const WgradPara
     const bool vec_ok = !atomic && (p.Cin & 3) == 0 && ((uintptr_t)p.dw & 15) == 0;
     // workgroups that add into the same tile (different pixel ranges) finish together: each starts at a different row block so
     // that their atomics do not queue on the same addresses
+    if (p.slabs) {
+        // slab mode: the whole 256 x 256 partial tile, dense, as plain 16-B stores (1 KB per row and wave-instruction) -- fp32 atomics
+        // top out at 1.5 TB/s chip-wide and cost a workgroup 60-90 k cycles; wgrad_slab_sum_kernel adds the partials in range order
+        float *dst = p.slabs + (long)part * (TCO * TCI);
+        auto spass = [&](auto hc) {
+            constexpr int h = decltype(hc)::value;
+            __syncthreads();
+            if (wco == (h >> 1)) {
+#pragma unroll
+                for (int ii = 0; ii < 2; ++ii) {
+                    constexpr int i0 = (h & 1) * 2;
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r)
+                            ot[(ii * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * TCI + wci * 64 + j * 32 + (lane & 31)] = acc[i0 + ii][j][r];
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int idx = k * NTHR + tid, row = idx >> 6, c4 = (idx & 63) * 4;
+                *reinterpret_cast<float4 *>(dst + (h * 64 + row) * TCI + c4) = *reinterpret_cast<const float4 *>(ot + row * TCI + c4);
+            }
+        };
+        spass(std::integral_constant<int, 0>{});
+        spass(std::integral_constant<int, 1>{});
+        spass(std::integral_constant<int, 2>{});
+        spass(std::integral_constant<int, 3>{});
+        return;
+    }
     const int rot = (int)((pbeg / BP) % 127);
     auto pass = [&](auto hc) {          // 64 co rows h * 64 .. of the tile; h is static: the accumulators must stay in registers
         constexpr int h = decltype(hc)::value;
@@ -428,6 +460,42 @@ __global__ void __launch_bounds__(wp::NTHR, 2) wgrad_pipe_kernel(const WgradPara
     }
 #endif
 #undef KSTAMP
+}
+
+// Sum of the partial tiles of slab mode into the packed gradient dw[co][tap][ci]: one thread = 4 consecutive columns of one tile row,
+// partials added in range order (fixed: the result does not depend on the order in which the workgroups ran).
+__global__ void __launch_bounds__(256) wgrad_slab_sum_kernel(const float *__restrict__ slabs, float *__restrict__ dw, int Cout, int Cin, int ntaps, int n_co_tiles,
+                                                             int n_ci_tiles, int tile_taps, int main_tiles, int main_split, int tail_split, int main_ranges,
+                                                             int tail_ranges)
+{
+    using namespace wp;
+    const int bid = blockIdx.y;                                   // tile
+    const int idx = blockIdx.x * 256 + threadIdx.x;               // float4 inside the tile: row = idx / 64
+    const int row = idx >> 6, c4 = (idx & 63) * 4;
+    const int co_tile = bid % n_co_tiles, rest = bid / n_co_tiles;
+    const int ci_tile = rest % n_ci_tiles, tap0 = (rest / n_ci_tiles) * tile_taps;
+    const int co = co_tile * TCO + row;
+    const int col_lim = tile_taps > 1 ? min(TCI, (ntaps - tap0) * Cin) : min(TCI, Cin - ci_tile * TCI);
+    if (co >= Cout || c4 >= col_lim) return;
+    const bool tail = bid >= main_tiles;
+    const long first = tail ? (long)main_tiles * main_split + (long)(bid - main_tiles) * tail_split : (long)bid * main_split;
+    const int n = tail ? tail_ranges : main_ranges;
+    const float *src = slabs + first * (TCO * TCI) + row * TCI + c4;
+    float4 a = *reinterpret_cast<const float4 *>(src);
+    for (int r = 1; r < n; ++r) {
+        const float4 b = *reinterpret_cast<const float4 *>(src + (long)r * (TCO * TCI));
+        a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    }
+    const long col0 = tile_taps > 1 ? (long)tap0 * Cin : (long)tap0 * Cin + ci_tile * TCI;
+    *reinterpret_cast<float4 *>(dw + (long)co * ntaps * Cin + col0 + c4) = a;
+}
+
+int wgrad_slab_sum_launch(const WgradParams &p, int tiles, int main_ranges, int tail_ranges, hipStream_t s)
+{
+    hipLaunchKernelGGL(wgrad_slab_sum_kernel, dim3(wp::TCO * wp::TCI / 4 / 256, (unsigned)tiles), dim3(256), 0, s, (const float *)p.slabs, p.dw, p.Cout, p.Cin, p.ntaps,
+                       p.n_co_tiles, p.n_ci_tiles, p.tile_taps, p.seg ? p.main_tiles : tiles, p.seg ? p.main_split : main_ranges, p.seg ? p.tail_split : 1,
+                       main_ranges, tail_ranges);
+    return check_launch("yolo_wgrad (slab sum)");
 }
 
 int wgrad_pipe_launch(const WgradParams &p, dim3 grid, hipStream_t s)

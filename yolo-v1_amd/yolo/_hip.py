@@ -59,6 +59,7 @@ class WgradDesc(ctypes.Structure):
         ("geo_W", ctypes.c_int32), ("geo_H", ctypes.c_int32), ("geo_img_slots", ctypes.c_int32), ("geo_row_slots", ctypes.c_int32),
         ("geo_px_slots", ctypes.c_int32), ("geo_slot0", ctypes.c_int32),
         ("dw_sumsq", ctypes.c_void_p),
+        ("slabs", ctypes.c_void_p), ("slab_floats", ctypes.c_int64),
     ]
 
 
@@ -110,6 +111,7 @@ _SIGS = {
     "yolo_igemm": [ctypes.POINTER(IgemmDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
     "yolo_igemm_finish": [ctypes.POINTER(IgemmDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
     "yolo_wgrad": [ctypes.POINTER(WgradDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
+    "yolo_wgrad_slab_floats": [ctypes.POINTER(WgradDesc), ctypes.POINTER(ctypes.c_long)],
     "yolo_conv_stem7_fwd": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_long, c_int, c_float, c_int, c_void_p, c_long, c_int, c_int, c_void_p, c_long,
                             c_int, c_int, c_void_p],
     "yolo_wgrad_stem7": [c_void_p, c_void_p, c_int, c_int, c_int, c_long, c_int, c_long, c_int, c_int, c_void_p, c_void_p, c_void_p, c_long, c_void_p],

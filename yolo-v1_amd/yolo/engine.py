@@ -47,6 +47,11 @@ STRIDE2_CLASSES = True  # data gradient of a stride-2 3x3 conv as four parity-cl
 _SIDE_STREAMS: dict = {}
 SIDE_LOW = True      # ... of the lowest scheduling priority: the dispatcher prefers the data-gradient chain (12.73 -> 12.55 ms per step)
 WGRAD_STREAM = True  # backward: weight gradients run on a second HIP stream beside the data-gradient chain (they are off its critical path)
+WGRAD_SLABS = False  # pipelined weight-gradient kernel: partial tiles stored as slabs and summed in fixed order instead of fp32 atomics on the
+                     # gradient (yolo_wgrad_desc.slabs): bit-reproducible gradients, and 13-16 % faster per launch when the launch has the
+                     # chip to itself (conv10: 0.178 -> 0.150 ms) -- but the step as scheduled (weight gradients beside the data-gradient
+                     # chain) gets SLOWER, 12.06 -> 12.28 ms: the slabs' 2 x 64 MB per layer compete with the chain's HBM-bound epilogues,
+                     # while the atomics' traffic overlaps them.  Off by default; switch on for reproducible training runs.
 WGRAD_PIPE = True  # weight gradient of the big deep 3x3 layers through wgrad_pipe.hip (yolo_wgrad_desc.variant = 5)
 FC_NORM_IN_WGRAD = 1 << 26   # Linear layers with at least this many weights: yolo_wgrad also sums the squares of the gradient it stores
 POOL_CODES = True  # training: a fused conv + pool stores the pooled map and 2-bit arg-max codes, not the un-pooled activation
@@ -177,6 +182,23 @@ def _splitk_scratch(n: int, zero: bool) -> torch.Tensor:
     if zero:
         v.zero_()
     return v
+
+
+_WGRAD_SLAB_BUF: dict = {}
+
+
+def _attach_wgrad_slabs(L_, wd: WgradDesc, dev) -> None:
+    """slab mode of the pipelined weight-gradient kernel (yolo_wgrad_desc.slabs): partial tiles as plain stores + a fixed-order sum
+    instead of fp32 atomics.  One scratch per device, grown on demand (the launches of one stream use it one after the other)."""
+    need = ctypes.c_long(0)
+    check(L_.yolo_wgrad_slab_floats(ctypes.byref(wd), ctypes.byref(need)), "wgrad_slab_floats")
+    if need.value <= 0:
+        return
+    key = torch.device(dev).index
+    buf = _WGRAD_SLAB_BUF.get(key)
+    if buf is None or buf.numel() < need.value:
+        buf = _WGRAD_SLAB_BUF[key] = torch.empty(need.value, dtype=torch.float32, device=dev)
+    wd.slabs, wd.slab_floats = buf.data_ptr(), buf.numel()
 
 
 def _pipe_ok(d: IgemmDesc) -> bool:
@@ -1239,6 +1261,8 @@ class Plan:
                         # (measured: worth it from 28x28 down and for stride 2; at 56x56 and above the halo is < 8 % of the slots
                         # and the per-row coordinate arithmetic costs more than it saves)
                         wd = self._wgrad_desc(L, g, xin, N)
+                        if WGRAD_SLABS and wd.variant == 5:
+                            _attach_wgrad_slabs(L_, wd, dev)
                         with _timed(f"conv{li}.wgrad", "wgrad", 2.0 * N * L.Hout * L.Wout * L.Cout * L.Cin * L.K * L.K):
                             check(L_.yolo_wgrad(ctypes.byref(wd), xin.p, g.p, ptr(dwp), ptr(db), wst), f"wgrad conv{li}")
                     if not stem_direct:
