@@ -420,6 +420,13 @@ typedef struct yolo_adam_tensor {
 int yolo_sumsq_f32_multi(const float *const *g, const long *n, int count, double *acc, yolo_stream_t stream);
 int yolo_adam_step_multi(const yolo_adam_tensor *t, int count, float lr, float beta1, float beta2, float eps,
                          float weight_decay, long step, const double *norm_sq, float max_norm, yolo_stream_t stream);
+/* The same update as a BACKGROUND pass: `workgroups` (1 .. 256) persistent workgroups of 1024 threads, each holding one CU to itself
+ * (they reserve LDS they do not use), walk the elements.  An HBM-bound pass that occupies exactly that many CUs: launched on a
+ * second stream it runs beside MFMA-bound kernels on the other CUs -- e.g. the update of the Linear layers (76 % of this model's
+ * optimizer bytes, first used at the END of the next forward) beside the next forward's conv stack.  At most YOLO_MT_MAX tensors. */
+int yolo_adam_step_multi_bg(const yolo_adam_tensor *t, int count, float lr, float beta1, float beta2, float eps,
+                            float weight_decay, long step, const double *norm_sq, float max_norm, int workgroups,
+                            yolo_stream_t stream);
 /* g *= min(1, max_norm / (sqrt(*norm_sq) + 1e-6))  (stand-alone clip_grad_norm_ for other optimizers). */
 int yolo_clip_scale_f32(float *g, long n, const double *norm_sq, float max_norm, yolo_stream_t stream);
 

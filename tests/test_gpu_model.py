@@ -369,6 +369,47 @@ def test_adam_refreshes_linear_bf16_operands():
     assert torch.equal(y1, y2) and torch.equal(y1, y3)
 
 
+def test_adam_background_update_of_the_linear_layers():
+    """Adam.attach_plan(plan, overlap=True): the Linear layers are updated by a background pass on a second stream
+    (yolo_adam_step_multi_bg); the plan's next forward waits for it, optimizer.synchronize() / state_dict() make the current
+    stream wait.  Three steps give the same parameters, optimizer state and outputs as the foreground update."""
+    import copy
+    import torch.nn as nn
+    from yolo import engine
+    from yolo.optim import Adam
+    torch.manual_seed(3)
+    base = nn.Sequential(nn.Conv2d(64, 64, 3, padding=1), nn.LeakyReLU(0.1), nn.Flatten(), nn.Linear(64 * 6 * 6, 4096), nn.LeakyReLU(0.1),
+                         nn.Dropout(0.5), nn.Linear(4096, 30)).cuda().eval()
+    x = torch.randn(4, 64, 6, 6, device="cuda")
+    outs = {}
+    for overlap in (False, True):
+        mods = copy.deepcopy(base)
+        plan = engine.Plan.from_modules(list(mods), 64, False)
+        opt = Adam(mods.parameters(), lr=1e-2, weight_decay=5e-4, max_grad_norm=1.0)
+        opt.attach_plan(plan, overlap=overlap)
+        assert bool(opt.deferred) == overlap
+        ys = []
+        for it in range(3):
+            opt.zero_grad(set_to_none=True)
+            y = engine.run_plan(plan, x, False)          # waits for the previous step's background pass in front of the Linear layers
+            ys.append(y.detach().clone())
+            y.square().mean().backward()
+            opt.step()
+        sd = opt.state_dict()                            # synchronises
+        outs[overlap] = (ys, [p.detach().clone() for p in mods.parameters()],
+                         [sd["state"][k]["exp_avg_sq"].clone() for k in sorted(sd["state"])])
+    # (the two kernels are compiled separately: the compiler may contract a * b + c differently, hence a tolerance of a few ulp; a
+    # forward that missed the update would be off by the whole step, lr = 1e-2)
+    assert torch.equal(outs[False][0][0], outs[True][0][0])
+    for a, b in zip(outs[False][0], outs[True][0]):
+        torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-5, msg="forward outputs differ: the forward did not wait for (or did not see) the background update")
+    # parameters / second moments: the conv layer's weight gradient is summed with fp32 atomics (run-to-run differences of ~1e-9), which
+    # Adam's m / (sqrt(v) + eps) magnifies on elements with gradients near eps; a missed update would be off by lr = 1e-2
+    for group, atol in ((1, 5e-5), (2, 1e-7)):
+        for a, b in zip(outs[False][group], outs[True][group]):
+            torch.testing.assert_close(a, b, rtol=1e-3, atol=atol)
+
+
 def test_detection_head_on_the_engine():
     """DetectionHead (conv 3x3 x4 incl. stride 2, Flatten, FC) forward + backward on the HIP plan vs the
     bf16-faithful stock-torch reference (narrow input so that the CPU side stays cheap)."""

@@ -178,6 +178,92 @@ __global__ void __launch_bounds__(256) adam_multi_kernel(const AdamTable tab, fl
     }
 }
 
+// Background form (yolo_adam_step_multi_bg): `gridDim.x` PERSISTENT workgroups of 1024 threads walk the chunk list; the dynamic LDS
+// they reserve (unused) keeps every other workgroup off their CU.  The pass then occupies exactly gridDim.x CUs -- HBM-bound work that
+// runs beside the next forward's MFMA-bound conv stack on the remaining CUs instead of in front of it (a grid of 25 k small
+// workgroups would starve, or be starved by, the conv kernels, whose workgroups need a whole CU each).  Four float4 per array and
+// thread are in flight: ~190 KB per CU, what ~100 GB/s per CU needs at HBM latency.
+__global__ void __launch_bounds__(1024) adam_multi_bg_kernel(const AdamTable tab, int chunks, float b1, float b2, float eps, float wd, float step_size,
+                                                             float inv_bc2_sqrt, const double *__restrict__ norm_sq, float max_norm)
+{
+    float clip = 1.0f;
+    if (norm_sq) {
+        const float total = (float)sqrt(*norm_sq);
+        const float c = max_norm / (total + 1e-6f);
+        clip = c < 1.0f ? c : 1.0f;
+    }
+    // chunk = MT_CHUNK elements = 1024 threads x 2 x float4; the loads of the NEXT chunk are issued before the current one is computed
+    // and stored, so that a CU always has ~128-256 KB in flight (without the prefetch a pass on 48 CUs reached 44 GB/s per CU)
+    struct Vals {
+        float4 p[2], g[2], m[2], v[2];
+    };
+    auto where = [&](int b, int &ti, long &beg, bool &full) {
+        ti = find_tensor(tab.first, tab.count, b);
+        beg = (long)(b - tab.first[ti]) * MT_CHUNK;
+        full = beg + MT_CHUNK <= tab.t[ti].n;
+    };
+    auto load = [&](int ti, long beg, Vals &x) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const long i = beg + (long)(u * 1024 + threadIdx.x) * 4;
+            x.p[u] = *reinterpret_cast<const float4 *>(tab.t[ti].p + i);
+            x.g[u] = *reinterpret_cast<const float4 *>(tab.t[ti].g + i);
+            x.m[u] = *reinterpret_cast<const float4 *>(tab.t[ti].m + i);
+            x.v[u] = *reinterpret_cast<const float4 *>(tab.t[ti].v + i);
+        }
+    };
+    int b = blockIdx.x;
+    int ti = 0, nti = 0;
+    long beg = 0, nbeg = 0;
+    bool full = false, nfull = false;
+    Vals cur, nxt;
+    if (b < chunks) {
+        where(b, ti, beg, full);
+        if (full) load(ti, beg, cur);
+    }
+    while (b < chunks) {
+        const int nb = b + (int)gridDim.x;
+        if (nb < chunks) {
+            where(nb, nti, nbeg, nfull);
+            if (nfull) load(nti, nbeg, nxt);
+        }
+        float *__restrict__ p = tab.t[ti].p;
+        float *__restrict__ m = tab.t[ti].m;
+        float *__restrict__ v = tab.t[ti].v;
+        bf16_t *__restrict__ pb = (bf16_t *)tab.t[ti].p_bf16;
+        if (full) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const long i = beg + (long)(u * 1024 + threadIdx.x) * 4;
+                adam1(cur.p[u].x, cur.g[u].x, cur.m[u].x, cur.v[u].x, clip, wd, b1, b2, step_size, inv_bc2_sqrt, eps);
+                adam1(cur.p[u].y, cur.g[u].y, cur.m[u].y, cur.v[u].y, clip, wd, b1, b2, step_size, inv_bc2_sqrt, eps);
+                adam1(cur.p[u].z, cur.g[u].z, cur.m[u].z, cur.v[u].z, clip, wd, b1, b2, step_size, inv_bc2_sqrt, eps);
+                adam1(cur.p[u].w, cur.g[u].w, cur.m[u].w, cur.v[u].w, clip, wd, b1, b2, step_size, inv_bc2_sqrt, eps);
+                *reinterpret_cast<float4 *>(p + i) = cur.p[u];
+                *reinterpret_cast<float4 *>(m + i) = cur.m[u];
+                *reinterpret_cast<float4 *>(v + i) = cur.v[u];
+                if (pb) {
+                    uint2 o;
+                    o.x = (unsigned)f32_to_bf16(cur.p[u].x) | ((unsigned)f32_to_bf16(cur.p[u].y) << 16);
+                    o.y = (unsigned)f32_to_bf16(cur.p[u].z) | ((unsigned)f32_to_bf16(cur.p[u].w) << 16);
+                    *reinterpret_cast<uint2 *>(pb + i) = o;
+                }
+            }
+        } else {
+            const float *__restrict__ g = tab.t[ti].g;
+            const long end = min(tab.t[ti].n, beg + MT_CHUNK);
+            for (long k = beg + threadIdx.x; k < end; k += 1024) {     // last, partial chunk of a tensor
+                float pk = p[k], mk = m[k], vk = v[k];
+                adam1(pk, g[k], mk, vk, clip, wd, b1, b2, step_size, inv_bc2_sqrt, eps);
+                p[k] = pk; m[k] = mk; v[k] = vk;
+                if (pb) pb[k] = f32_to_bf16(pk);
+            }
+        }
+        b = nb; ti = nti; beg = nbeg; full = nfull;
+        cur = nxt;
+    }
+}
+
 __global__ void scale_by_clip_kernel(float *__restrict__ g, long n, const double *__restrict__ norm_sq, float max_norm)
 {
     const float total = (float)sqrt(*norm_sq);
@@ -283,6 +369,43 @@ YOLO_API int yolo_adam_step_multi(const yolo_adam_tensor *t, int count, float lr
         base += k;
     }
     return 0;
+}
+
+YOLO_API int yolo_adam_step_multi_bg(const yolo_adam_tensor *t, int count, float lr, float beta1, float beta2, float eps, float weight_decay, long step,
+                                     const double *norm_sq, float max_norm, int workgroups, yolo_stream_t stream)
+{
+    if (!t || count < 0 || count > YOLO_MT_MAX || step < 1 || workgroups < 1 || workgroups > 256)
+        return fail(YOLO_E_ARG, "yolo_adam_step_multi_bg: bad argument (at most %d tensors, 1 .. 256 workgroups)", YOLO_MT_MAX);
+    const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+    const float step_size = (float)((double)lr / bc1);
+    const float inv_bc2_sqrt = (float)(1.0 / sqrt(bc2));
+    AdamTable tab{};
+    long chunks = 0;
+    for (int k = 0; k < count; ++k) {
+        const yolo_adam_tensor &e = t[k];
+        if (!e.p || !e.g || !e.m || !e.v || e.n < 0) return fail(YOLO_E_ARG, "yolo_adam_step_multi_bg: tensor %d: null pointer or negative size", k);
+        if (((uintptr_t)e.p | (uintptr_t)e.g | (uintptr_t)e.m | (uintptr_t)e.v) & 15) return fail(YOLO_E_UNSUPPORTED, "yolo_adam_step_multi_bg: tensor %d is not 16-B aligned", k);
+        if ((uintptr_t)e.p_bf16 & 7) return fail(YOLO_E_UNSUPPORTED, "yolo_adam_step_multi_bg: bf16 shadow %d is not 8-B aligned", k);
+        tab.t[k] = e; tab.first[k] = (int)chunks;
+        chunks += (e.n + MT_CHUNK - 1) / MT_CHUNK;
+        if (chunks > 0x7fffffffL) return fail(YOLO_E_UNSUPPORTED, "yolo_adam_step_multi_bg: too many elements");
+    }
+    tab.first[count] = (int)chunks;
+    tab.count = count;
+    if (chunks == 0) return 0;
+    constexpr int BG_LDS = 96 * 1024;       // with 1024 threads: one such workgroup per CU, and no 128-KB conv workgroup beside it
+    static bool attr_done[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    if (!attr_done[dev]) {
+        hipError_t e = hipFuncSetAttribute((const void *)adam_multi_bg_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, BG_LDS);
+        if (e != hipSuccess) return fail((int)e, "yolo_adam_step_multi_bg: hipFuncSetAttribute(%d B LDS): %s", BG_LDS, hipGetErrorString(e));
+        attr_done[dev] = true;
+    }
+    const int G = (int)std::min<long>(workgroups, chunks);
+    hipLaunchKernelGGL(adam_multi_bg_kernel, dim3((unsigned)G), dim3(1024), BG_LDS, STRM(stream), tab, (int)chunks, beta1, beta2, eps, weight_decay, step_size, inv_bc2_sqrt,
+                       norm_sq, max_norm);
+    return check_launch("yolo_adam_step_multi_bg");
 }
 
 YOLO_API int yolo_clip_scale_f32(float *g, long n, const double *norm_sq, float max_norm, yolo_stream_t stream)

@@ -148,6 +148,7 @@ _SIGS = {
     "yolo_unpack_conv_wgrads_multi": [ctypes.POINTER(ConvUnpackItem), c_int, c_void_p],
     "yolo_sumsq_f32_multi": [c_void_p, c_void_p, c_int, c_void_p, c_void_p],
     "yolo_adam_step_multi": [ctypes.POINTER(AdamTensor), c_int, c_float, c_float, c_float, c_float, c_float, c_long, c_void_p, c_float, c_void_p],
+    "yolo_adam_step_multi_bg": [ctypes.POINTER(AdamTensor), c_int, c_float, c_float, c_float, c_float, c_float, c_long, c_void_p, c_float, c_int, c_void_p],
     "yolo_bias_lrelu_rows": [c_void_p, c_void_p, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p],
     "yolo_bias_lrelu_rows_slabs": [c_void_p, c_int, c_void_p, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p],
 }

@@ -45,6 +45,7 @@ STEM_KERNEL = True  # 7x7/s2 stem through yolo_conv_stem7_fwd (False: the generi
 STEM_POOL_BWD_FUSED = True  # backward of the pool + LeakyReLU behind the stem inside yolo_wgrad_stem7_pooled (False: separate pass)
 STRIDE2_CLASSES = True  # data gradient of a stride-2 3x3 conv as four parity-class convs over the non-zero gradient slots
 _SIDE_STREAMS: dict = {}
+_PARAMS_READY: dict = {}     # id(plan) -> event behind a background optimizer launch (yolo.optim.Adam.attach_plan(overlap=True))
 SIDE_LOW = True      # ... of the lowest scheduling priority: the dispatcher prefers the data-gradient chain (12.73 -> 12.55 ms per step)
 WGRAD_STREAM = True  # backward: weight gradients run on a second HIP stream beside the data-gradient chain (they are off its critical path)
 WGRAD_SLABS = False  # pipelined weight-gradient kernel: partial tiles stored as slabs and summed in fixed order instead of fp32 atomics on the
@@ -716,6 +717,10 @@ class Plan:
         self._pfb[li] = (key, wb)
         return wb
 
+    def fc_biases(self):
+        """bias parameters of the Linear layers on the device (updated together with their weights, yolo.optim.Adam.attach_plan)"""
+        return [L.bias for L in self.layers if L.kind == "fc" and L.bias is not None and L.bias.is_cuda]
+
     def bf16_shadows(self):
         """[(param, bf16 forward operand with the master's layout, callback)] for the Linear layers: an optimizer
         that writes bf16(p) into the operand while it updates p calls ``callback(p)`` afterwards
@@ -925,6 +930,9 @@ class Plan:
                 check(L_.yolo_nhwc_bf16_to_nchw_bf16(cur.p, N, cur.C, cur.H, cur.W, cur.halo, ptr(nxt), st), "flatten")
                 cur = nxt
             elif L.kind == "fc":
+                ev = _PARAMS_READY.pop(id(self), None)
+                if ev is not None:       # yolo.optim.Adam(overlap): the Linear layers' update of the last step runs on a second stream
+                    torch.cuda.current_stream(dev).wait_event(ev)
                 if train:
                     wf, _ = self._pack(li, False)
                 else:

@@ -18,6 +18,11 @@ from . import _hip
 from ._hip import AdamTensor, check, lib, ptr, stream
 
 
+BG_CUS = 64        # CUs the background update of the Linear layers holds (yolo_adam_step_multi_bg): a CU streams ~42 GB/s whatever it keeps in flight,
+                   # so the pass runs at 2.6 TB/s there (2.4 ms) -- under the conv stack of the next forward; 24 CUs: too slow (step 13.9 ms), 96: same as 64
+OVERLAP = True     # attach_plan(overlap=True) takes effect (switch for in-process A/B runs)
+
+
 def _f32c(g: torch.Tensor) -> torch.Tensor:
     return g if (g.dtype == torch.float32 and g.is_contiguous()) else g.float().contiguous()
 
@@ -76,6 +81,13 @@ class Adam(torch.optim.Optimizer):
         self.max_grad_norm = max_grad_norm
         self.bf16_shadow: dict[int, tuple] = {}   # id(param) -> (bf16 tensor refreshed in the same pass, callback(param) | None)
         self.plans: list = []                     # attached engine plans: their backward passes leave squared gradient norms (grad_norm_sq)
+        # attach_plan(plan, overlap=True): id(param) -> plan.  The update of these parameters (the Linear layers: 76 % of the model's
+        # optimizer bytes, first used at the END of the next forward) runs as a background pass on BG_CUS CUs of a second stream
+        # (yolo_adam_step_multi_bg) beside the next forward's conv stack; the plan's forward waits for it in front of its first
+        # Linear layer.
+        self.deferred: dict[int, object] = {}
+        self._side = None
+        self._pending = None                      # event behind the last background launch
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -97,10 +109,12 @@ class Adam(torch.optim.Optimizer):
             plan.grad_norm_sq.clear()          # one backward pass, one use
         norm = grad_norm_sq(all_params, known) if self.max_grad_norm is not None else None
         st = stream()
+        main_t = torch.cuda.current_stream()
+        side_used = False
         for group in self.param_groups:
             b1, b2 = group["betas"]
-            # one launch per (group, step count): normally ONE launch for the whole model
-            by_step: dict[int, list] = {}
+            # one launch per (group, step count, foreground / background): normally one for the conv stack and one for the Linear layers
+            by_step: dict[tuple, list] = {}
             keep = []                      # temporaries the launch reads must outlive the enqueue
             for p in group["params"]:
                 if p.grad is None:
@@ -117,25 +131,76 @@ class Adam(torch.optim.Optimizer):
                 state["step"] += 1
                 hook = self.bf16_shadow.get(id(p))
                 shadow = hook[0] if hook is not None else None
-                by_step.setdefault(int(state["step"].item()), []).append(
+                late = OVERLAP and id(p) in self.deferred
+                if late:
+                    g.record_stream(self._side_stream())     # read on the second stream after the caller may have dropped it
+                by_step.setdefault((int(state["step"].item()), late), []).append(
                     (p, AdamTensor(p.data_ptr(), g.data_ptr(), state["exp_avg"].data_ptr(), state["exp_avg_sq"].data_ptr(),
                                    shadow.data_ptr() if shadow is not None else None, p.numel()), hook))
-            for step, items in by_step.items():
+            for (step, late), items in sorted(by_step.items(), key=lambda kv: kv[0][1]):      # the foreground launch first
                 tab = (AdamTensor * len(items))(*[it[1] for it in items])
-                check(lib().yolo_adam_step_multi(tab, len(items), float(group["lr"]), float(b1), float(b2), float(group["eps"]),
-                                                 float(group["weight_decay"]), step, ptr(norm), float(self.max_grad_norm or 0.0), st), "yolo_adam_step_multi")
+                if late and len(items) <= 48:
+                    side = self._side_stream()
+                    if not side_used:
+                        side.wait_stream(main_t)             # behind the gradients, the norm and the last forward's / backward's reads
+                        if norm is not None:
+                            norm.record_stream(side)
+                        side_used = True
+                    check(lib().yolo_adam_step_multi_bg(tab, len(items), float(group["lr"]), float(b1), float(b2), float(group["eps"]),
+                                                        float(group["weight_decay"]), step, ptr(norm), float(self.max_grad_norm or 0.0), BG_CUS,
+                                                        ctypes.c_void_p(side.cuda_stream)), "yolo_adam_step_multi_bg")
+                else:
+                    check(lib().yolo_adam_step_multi(tab, len(items), float(group["lr"]), float(b1), float(b2), float(group["eps"]),
+                                                     float(group["weight_decay"]), step, ptr(norm), float(self.max_grad_norm or 0.0), st), "yolo_adam_step_multi")
                 for p, _, hook in items:
                     # the kernel updated p through a raw pointer: bump the autograd version so that the
                     # engine's packed bf16 copies notice (no memory traffic) ...
                     torch.autograd.graph.increment_version(p)
                     if hook is not None and hook[1] is not None:
                         hook[1](p)         # ... and tell the owner of a shadow that it is already current
+        if side_used:
+            ev = torch.cuda.Event()
+            ev.record(self._side)
+            self._pending = ev
+            from . import engine
+            for plan in self.deferred.values():
+                engine._PARAMS_READY[id(plan)] = ev     # Plan.forward waits for it in front of its first Linear layer
         return loss
 
-    def attach_plan(self, plan) -> None:
+    def _side_stream(self):
+        if self._side is None:
+            self._side = _hip.side_stream(torch.device("cuda", torch.cuda.current_device()), low=False)
+        return self._side
+
+    def synchronize(self) -> None:
+        """Make the CURRENT stream wait for a background update still running on the second stream (attach_plan(overlap=True)).
+        The attached plan's forward does this by itself in front of its Linear layers; call it before reading those layers'
+        parameters or the optimizer state in any other way (state_dict() and zero_grad(set_to_none=False) do)."""
+        if self._pending is not None:
+            torch.cuda.current_stream().wait_event(self._pending)
+            self._pending = None
+
+    def state_dict(self):
+        self.synchronize()
+        return super().state_dict()
+
+    def zero_grad(self, set_to_none: bool = True):
+        if not set_to_none:
+            self.synchronize()             # zeroing in place would race with the background pass, which still reads the gradients
+        return super().zero_grad(set_to_none=set_to_none)
+
+    def attach_plan(self, plan, overlap: bool = False) -> None:
         """Let this optimizer refresh the engine's bf16 forward operands of Linear layers in the same
-        pass that updates their fp32 masters (``plan``: ``model.hip_plan()``)."""
+        pass that updates their fp32 masters (``plan``: ``model.hip_plan()``).
+
+        ``overlap``: update the Linear layers as a background pass on a second stream, beside the next forward's conv stack (same
+        floats; see ``synchronize`` for what then has to wait).  The training loop and bench.py switch it on."""
         for p, shadow, fresh in plan.bf16_shadows():
             self.bf16_shadow[id(p)] = (shadow, fresh)
+            if overlap:
+                self.deferred[id(p)] = plan
+        if overlap:
+            for b in plan.fc_biases():
+                self.deferred[id(b)] = plan
         if all(pl is not plan for pl in self.plans):
             self.plans.append(plan)
