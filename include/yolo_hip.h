@@ -298,6 +298,9 @@ int yolo_pack_fc_weight(const float *w, int O, int C, int HW, void *w_fwd_bf16, 
  * With yolo_igemm_desc.w_blocked = 1 each LDS stage of the weight stream is one contiguous 16-KB read
  * (a Linear layer at batch 64 is HBM-bound on its 822 MB / 411 MB weight). */
 int yolo_pack_fc_weight_blocked(const float *w, int O, long K, void *w_panels_bf16, yolo_stream_t stream);
+/* The same panels with the K axis permuted from (c, hw) -- nn.Flatten of an NCHW map (models.py:239) -- to (hw, c): the Linear layer
+ * then reads a dense NHWC conv output as it lies in memory and the flatten pass disappears (inference). */
+int yolo_pack_fc_weight_blocked_hwc(const float *w, int O, int C, int HW, void *w_panels_bf16, yolo_stream_t stream);
 /* packed fp32 gradient [Cout][KH][KWp][Cinp] -> OIHW fp32 (accumulate=0: overwrite, 1: add). */
 int yolo_unpack_conv_wgrad(const float *dw_packed, int Cout, int Cin, int KH, int KW, int Cinp, int KWp,
                            float *dw_oihw, int accumulate, yolo_stream_t stream);

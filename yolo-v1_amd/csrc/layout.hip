@@ -288,6 +288,35 @@ __global__ void pack_fc_blocked_kernel(const float *__restrict__ w, int O, long 
     *reinterpret_cast<uint4 *>(wb + idx * 8) = out;
 }
 
+// the same panels with the K axis permuted from (c, hw) -- nn.Flatten of an NCHW map -- to (hw, c), the order in which a dense NHWC
+// map lies in memory: the Linear layer then reads the conv output directly and the flatten pass disappears (inference)
+__global__ void pack_fc_blocked_hwc_kernel(const float *__restrict__ w, int O, int C, int HW, bf16_t *__restrict__ wb)
+{
+    const long K = (long)C * HW, nk = K / 64;
+    const long total8 = (long)((O + 127) / 128) * nk * 128 * 8;
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total8) return;
+    const int c8 = (int)(idx & 7);
+    const int r = (int)((idx >> 3) & 127);
+    const long kt = (idx >> 10) % nk;
+    const long ct = (idx >> 10) / nk;
+    const long o = ct * 128 + r;
+    uint4 out = {0u, 0u, 0u, 0u};
+    if (o < O) {
+        const long kp = kt * 64 + c8 * 8;                 // (hw, c) position of the group's first element; C % 8 == 0: one hw
+        const long hw = kp / C, c = kp - hw * C;
+        const float *src = w + o * K + c * HW + hw;
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = src[(long)e * HW];
+        out.x = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
+        out.y = (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
+        out.z = (unsigned)f32_to_bf16(v[4]) | ((unsigned)f32_to_bf16(v[5]) << 16);
+        out.w = (unsigned)f32_to_bf16(v[6]) | ((unsigned)f32_to_bf16(v[7]) << 16);
+    }
+    *reinterpret_cast<uint4 *>(wb + idx * 8) = out;
+}
+
 // generic tiled transposes: [R][Cc] -> [Cc][R]
 template <typename TI, typename TO, typename CV>
 __device__ __forceinline__ void transpose_tile(const TI *__restrict__ x, long R, long Cc, TO *__restrict__ y, long ld, CV cv)
@@ -652,6 +681,15 @@ YOLO_API int yolo_im2col_rows(const void *x, long x_img_stride, int x_row_stride
     hipLaunchKernelGGL(im2col_rows_kernel, dim3(nblk(total, 256)), dim3(256), 0, STRM(stream), (const bf16_t *)x, x_img_stride, x_row_stride, x_px_stride, stride, KH, seg,
                        N, Ho, Wo, out_halo, (bf16_t *)xcol);
     return check_launch("yolo_im2col_rows");
+}
+
+YOLO_API int yolo_pack_fc_weight_blocked_hwc(const float *w, int O, int C, int HW, void *wb, yolo_stream_t stream)
+{
+    if (!w || !wb || O <= 0 || C <= 0 || HW <= 0 || (C & 7) || (((long)C * HW) & 63))
+        return fail(YOLO_E_ARG, "yolo_pack_fc_weight_blocked_hwc: bad argument (C must be a multiple of 8, C * HW of 64)");
+    const long total8 = (long)((O + 127) / 128) * ((long)C * HW / 64) * 128 * 8;
+    hipLaunchKernelGGL(pack_fc_blocked_hwc_kernel, dim3(nblk(total8, 256)), dim3(256), 0, STRM(stream), w, O, C, HW, (bf16_t *)wb);
+    return check_launch("yolo_pack_fc_weight_blocked_hwc");
 }
 
 YOLO_API int yolo_pack_fc_weight_blocked(const float *w, int O, long K, void *wb, yolo_stream_t stream)

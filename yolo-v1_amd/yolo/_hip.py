@@ -132,6 +132,7 @@ _SIGS = {
     "yolo_pack_conv_weight": [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p],
     "yolo_pack_fc_weight": [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p],
     "yolo_pack_fc_weight_blocked": [c_void_p, c_int, c_long, c_void_p, c_void_p],
+    "yolo_pack_fc_weight_blocked_hwc": [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p],
     "yolo_unpack_conv_wgrad": [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p],
     "yolo_im2col_rows": [c_void_p, c_long, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p],
     "yolo_transpose_f32_to_bf16": [c_void_p, c_int, c_int, c_void_p, c_int, c_void_p],

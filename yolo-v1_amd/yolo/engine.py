@@ -55,6 +55,7 @@ WGRAD_SLABS = False  # pipelined weight-gradient kernel: partial tiles stored as
                      # while the atomics' traffic overlaps them.  Off by default; switch on for reproducible training runs.
 WGRAD_PIPE = True  # weight gradient of the big deep 3x3 layers through wgrad_pipe.hip (yolo_wgrad_desc.variant = 5)
 FC_NORM_IN_WGRAD = 1 << 26   # Linear layers with at least this many weights: yolo_wgrad also sums the squares of the gradient it stores
+FLATTEN_FREE = True  # inference: conv -> nn.Flatten -> Linear without the flatten pass (dense NHWC conv output + K-permuted weight panels)
 POOL_CODES = True  # training: a fused conv + pool stores the pooled map and 2-bit arg-max codes, not the un-pooled activation
 FUSE_POOL = True   # inference: fold MaxPool2d(2,2) into the preceding conv's epilogue where the geometry allows
 
@@ -703,17 +704,21 @@ class Plan:
         self._pd2[li] = (key, panels)
         return panels
 
-    def _pack_fc_blocked(self, li: int):
+    def _pack_fc_blocked(self, li: int, hwc=None):
         """inference operand of a Linear layer: bf16 [O/128][K/64][128][64] panels (contiguous 16-KB stage reads; the
-        plain [O][K] copy that training shares with the optimizer streams ~15 % slower)."""
+        plain [O][K] copy that training shares with the optimizer streams ~15 % slower).  ``hwc = (C, HW)``: K axis permuted from
+        nn.Flatten's (c, hw) order to (hw, c) -- the layer then reads the dense NHWC conv output directly (FLATTEN_FREE)."""
         L = self.layers[li]
-        key = self._wkey(L.weight)
+        key = (self._wkey(L.weight), hwc)
         hit = self._pfb.get(li)
         if hit is not None and hit[0] == key:
             return hit[1]
         wsrc = self._src(L)
         wb = hit[1] if hit is not None else torch.empty((_round_up(L.Cout, 128) * L.Cin,), dtype=torch.bfloat16, device=L.weight.device)
-        check(lib().yolo_pack_fc_weight_blocked(ptr(wsrc), L.Cout, L.Cin, ptr(wb), stream()), "pack_fc_blocked")
+        if hwc is not None:
+            check(lib().yolo_pack_fc_weight_blocked_hwc(ptr(wsrc), L.Cout, hwc[0], hwc[1], ptr(wb), stream()), "pack_fc_blocked_hwc")
+        else:
+            check(lib().yolo_pack_fc_weight_blocked(ptr(wsrc), L.Cout, L.Cin, ptr(wb), stream()), "pack_fc_blocked")
         self._pfb[li] = (key, wb)
         return wb
 
@@ -758,7 +763,11 @@ class Plan:
                 L.Hin, L.Win = cur.H, cur.W
                 L.Hout = (cur.H + 2 * L.pad - L.K) // L.stride + 1
                 L.Wout = (cur.W + 2 * L.pad - L.K) // L.stride + 1
-                cur = Act(N, L.Hout, L.Wout, L.Cout, 1, device)
+                # inference, conv -> nn.Flatten -> Linear: the conv writes a dense NHWC map (no halo) that the Linear layer reads as it
+                # lies, through weight panels with a permuted K axis -- no flatten pass (FLATTEN_FREE)
+                dense = (not train and FLATTEN_FREE and li + 2 < len(self.layers) and self.layers[li + 1].kind == "flatten"
+                         and self.layers[li + 2].kind == "fc" and L.Cout % 8 == 0 and (L.Cout * L.Hout * L.Wout) % 64 == 0)
+                cur = Act(N, L.Hout, L.Wout, L.Cout, 0 if dense else 1, device)
             elif L.kind == "pool":
                 L.Hin, L.Win = cur.H, cur.W
                 cur = Act(N, cur.H // 2, cur.W // 2, cur.C, 1, device)
@@ -860,6 +869,7 @@ class Plan:
         # window position of the maximum; the backward pass needs nothing else of the un-pooled activation (debug_keep: the tests'
         # teacher-forced checks read that activation, so it is written instead)
         self.grad_norm_sq.clear()
+        hwc = None
         codes_mode = train and POOL_CODES and self.debug_keep is not True      # (debug_keep = "codes": keep the workspace of the product path)
         ws["codes"] = set()
         for li, L in enumerate(self.layers):
@@ -927,6 +937,10 @@ class Plan:
                     check(L_.yolo_maxpool2_fwd(ctypes.byref(pd), cur.p, nxt.p, st), "maxpool")
                 cur = nxt
             elif L.kind == "flatten":
+                if not train and isinstance(cur, Act) and cur.halo == 0 and cur.halo_hi == 0 and FLATTEN_FREE:
+                    hwc = (cur.C, cur.H * cur.W)            # the next Linear layer takes (hw, c)-ordered panels
+                    cur = cur.t.view(N, -1)
+                    continue
                 check(L_.yolo_nhwc_bf16_to_nchw_bf16(cur.p, N, cur.C, cur.H, cur.W, cur.halo, ptr(nxt), st), "flatten")
                 cur = nxt
             elif L.kind == "fc":
@@ -936,7 +950,8 @@ class Plan:
                 if train:
                     wf, _ = self._pack(li, False)
                 else:
-                    wf = self._pack_fc_blocked(li)
+                    wf = self._pack_fc_blocked(li, hwc)
+                    hwc = None
                 xin = cur  # (N, K) bf16
                 K = L.Cin
                 d = IgemmDesc()
