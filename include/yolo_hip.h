@@ -318,6 +318,12 @@ int yolo_conv_stem7_fwd(const void *x_nhwc4_bf16, const void *w_packed_bf16, con
                         long x_img_stride, int x_row_stride, float slope, int pool2, void *out_bf16,
                         long out_img_stride, int out_row_stride, int out_off, void *out_full_bf16,
                         long full_img_stride, int full_row_stride, int full_off, yolo_stream_t stream);
+/* The same from the caller's NCHW fp32 image batch [N][3][H][W] (H, W even; Ho = H/2, Wo = W/2): the input patch of a tile is
+ * converted to NHWC4 bf16 on its way into LDS (same rounding as yolo_nchw_f32_to_nhwc_bf16), so the separate layout pass and its
+ * 103 MB intermediate (batch 64) disappear.  Same results bit for bit. */
+int yolo_conv_stem7_fwd_f32(const float *x_nchw_f32, const void *w_packed_bf16, const float *bias, int N, int H, int W, float slope,
+                            int pool2, void *out_bf16, long out_img_stride, int out_row_stride, int out_off, void *out_full_bf16,
+                            long full_img_stride, int full_row_stride, int full_off, yolo_stream_t stream);
 /* Weight + bias gradient of the 7x7 / stride-2 / pad-3 stem conv (models.py:49; 3 input channels stored
  * NHWC4 with halo 3, Cout = 64) WITHOUT the unfolded copy: the unfolding happens in the LDS read addresses of
  * the MFMA operands.  dy: NHWC bf16 with 64 channels, dy_off = element offset of output pixel (0,0).

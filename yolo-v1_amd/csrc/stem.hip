@@ -48,8 +48,13 @@ struct StemFwdParams {
     unsigned short *codes;  // pool mode only, optional (pool2 = 3): arg-max codes instead, uint16 per (pooled pixel, 8 channels) at (pooled address) / 8
     long full_img_stride;
     int full_row_stride, full_off;
+    // F32IN: the input is the caller's NCHW fp32 tensor (3 planes of H x W): the patch is converted to NHWC4 bf16 on its way into LDS,
+    // so the separate layout pass (154 MB read + 103 MB written + 103 MB read again at batch 64) disappears
+    const float *x32;
+    int H, W;
 };
 
+template <bool F32IN>
 __global__ void __launch_bounds__(256, 2) stem_fwd_kernel(const StemFwdParams p)
 {
     __shared__ __attribute__((aligned(16))) char patchA[SF_X_BYTES];
@@ -88,6 +93,42 @@ __global__ void __launch_bounds__(256, 2) stem_fwd_kernel(const StemFwdParams p)
         const bf16_t *xb = p.x + (long)n * p.x_img_stride + (long)(ty * SF_TH * 2) * p.x_row_stride + tx * SF_TW * 2 * 4;
         STEM_GLDS16(xb + x_off[0], sb + wave * 1024);
         if (wave < 3) STEM_GLDS16(xb + x_off[1], sb + (4 + wave) * 1024);
+    };
+
+    // F32IN: this thread's (at most) two slots = 2 x 2 pixels x 3 planes, loaded into registers one tile ahead and written to LDS as
+    // NHWC4 bf16 (channel 3 = 0) after the MFMA phase of the current tile; pixels outside the image are the conv's zero padding
+    float xr[2][6];
+    auto f32_load = [&](int tile) {
+        const int tx = tile % p.tiles_x, r = tile / p.tiles_x;
+        const int ty = r % p.tiles_y, n = r / p.tiles_y;
+        const float *xb = p.x32 + (long)n * 3 * p.H * p.W;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            int slot = (i * 4 + wave) * 64 + lane;
+            if (slot >= SF_PH * (SF_PW / 2)) slot = SF_PH * (SF_PW / 2) - 1;
+            const int y = ty * SF_TH * 2 - 3 + slot / (SF_PW / 2), x0 = tx * SF_TW * 2 - 3 + (slot % (SF_PW / 2)) * 2;
+            const bool yin = y >= 0 && y < p.H && (i == 0 || wave < 3);
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int x = x0 + e;
+                const bool in = yin && x >= 0 && x < p.W;
+                const long o = (long)y * p.W + x;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) xr[i][e * 3 + c] = in ? xb[(long)c * p.H * p.W + o] : 0.0f;
+            }
+        }
+    };
+    auto f32_store = [&](char *sb) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            if (i == 1 && wave >= 3) continue;
+            uint4 o;
+            o.x = (unsigned)f32_to_bf16(xr[i][0]) | ((unsigned)f32_to_bf16(xr[i][1]) << 16);
+            o.y = (unsigned)f32_to_bf16(xr[i][2]);
+            o.z = (unsigned)f32_to_bf16(xr[i][3]) | ((unsigned)f32_to_bf16(xr[i][4]) << 16);
+            o.w = (unsigned)f32_to_bf16(xr[i][5]);
+            *reinterpret_cast<uint4 *>(sb + ((i * 4 + wave) * 64 + lane) * 16) = o;
+        }
     };
 
     // B fragment address of (local row rr of the wave, ky): pixel (2*(2*wave+rr) + ky, 2*n16 + 2*kb)
@@ -198,14 +239,27 @@ __global__ void __launch_bounds__(256, 2) stem_fwd_kernel(const StemFwdParams p)
 
     const int G = gridDim.x;
     int tile = blockIdx.x, prev = -1;
-    if (tile < p.ntiles) stage(patchA, tile);
+    if (tile < p.ntiles) {
+        if constexpr (F32IN) {
+            f32_load(tile);
+            f32_store(patchA);
+        } else {
+            stage(patchA, tile);
+        }
+    }
     while (tile < p.ntiles) {
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();   // patch A landed, otile B complete (tile prev), otile A free
         asm volatile("" ::: "memory");
-        if (tile + G < p.ntiles) stage(patchB, tile + G);
+        if (tile + G < p.ntiles) {
+            if constexpr (F32IN) f32_load(tile + G);
+            else stage(patchB, tile + G);
+        }
         if (prev >= 0) store_phase(otileB, prev);
         mfma_phase(patchA, otileA);
+        if constexpr (F32IN) {
+            if (tile + G < p.ntiles) f32_store(patchB);      // (patch B was last read before this iteration's barrier)
+        }
         prev = tile;
         tile += G;
         if (tile >= p.ntiles) {
@@ -218,9 +272,15 @@ __global__ void __launch_bounds__(256, 2) stem_fwd_kernel(const StemFwdParams p)
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        if (tile + G < p.ntiles) stage(patchA, tile + G);
+        if (tile + G < p.ntiles) {
+            if constexpr (F32IN) f32_load(tile + G);
+            else stage(patchA, tile + G);
+        }
         store_phase(otileA, prev);
         mfma_phase(patchB, otileB);
+        if constexpr (F32IN) {
+            if (tile + G < p.ntiles) f32_store(patchA);
+        }
         prev = tile;
         tile += G;
         if (tile >= p.ntiles) {
@@ -265,6 +325,38 @@ YOLO_API int yolo_conv_stem7_fwd(const void *x_nhwc4, const void *w_packed, cons
     }
     // persistent workgroups, 2 resident per CU (200 VGPRs): 512 .. 2048 measure the same
     const long G = std::min<long>(nt, 1024);
-    hipLaunchKernelGGL(stem_fwd_kernel, dim3((unsigned)G), dim3(256), 0, STRM(stream), p);
+    hipLaunchKernelGGL(stem_fwd_kernel<false>, dim3((unsigned)G), dim3(256), 0, STRM(stream), p);
     return check_launch("yolo_conv_stem7_fwd");
+}
+
+YOLO_API int yolo_conv_stem7_fwd_f32(const float *x_nchw, const void *w_packed, const float *bias, int N, int H, int W, float slope, int pool2, void *out,
+                                     long out_img_stride, int out_row_stride, int out_off, void *out_full, long full_img_stride, int full_row_stride, int full_off,
+                                     yolo_stream_t stream)
+{
+    const int Ho = H / 2, Wo = W / 2;
+    if (!x_nchw || !w_packed || !bias || !out || N <= 0 || H <= 0 || W <= 0 || (H & 1) || (W & 1)) return fail(YOLO_E_ARG, "yolo_conv_stem7_fwd_f32: bad argument");
+    if (pool2 == 3 && !out_full) return fail(YOLO_E_ARG, "yolo_conv_stem7_fwd_f32: pool2 = 3 writes the arg-max codes through out_full");
+    if (out_full && pool2 != 3 && (!pool2 || (full_row_stride & 7) || (full_img_stride & 7) || (full_off & 7) || ((uintptr_t)out_full & 15)))
+        return fail(YOLO_E_ARG, "yolo_conv_stem7_fwd_f32: out_full needs pool2 = 1 and strides in multiples of 8 elements");
+    if ((Ho % SF_TH) || (Wo % SF_TW)) return fail(YOLO_E_UNSUPPORTED, "yolo_conv_stem7_fwd_f32: output %dx%d is not a multiple of %dx%d", Ho, Wo, SF_TH, SF_TW);
+    if ((out_row_stride & 7) || (out_img_stride & 7) || (out_off & 7) || ((uintptr_t)out & 15) || ((uintptr_t)w_packed & 15))
+        return fail(YOLO_E_UNSUPPORTED, "yolo_conv_stem7_fwd_f32: strides must be multiples of 8 elements and pointers 16-B aligned");
+    StemFwdParams p{};
+    p.x32 = x_nchw; p.H = H; p.W = W;
+    p.w = (const bf16_t *)w_packed; p.bias = bias; p.out = (bf16_t *)out;
+    p.tiles_x = Wo / SF_TW; p.tiles_y = Ho / SF_TH;
+    const long nt = (long)N * p.tiles_x * p.tiles_y;
+    if (nt > 0x7fffffffL) return fail(YOLO_E_UNSUPPORTED, "yolo_conv_stem7_fwd_f32: too many tiles");
+    p.ntiles = (int)nt;
+    p.out_img_stride = out_img_stride; p.out_row_stride = out_row_stride; p.out_off = out_off;
+    p.pool = pool2 ? 1 : 0;
+    p.slope = slope;
+    if (pool2 == 3) {
+        p.codes = (unsigned short *)out_full;
+    } else {
+        p.full = (bf16_t *)out_full; p.full_img_stride = full_img_stride; p.full_row_stride = full_row_stride; p.full_off = full_off;
+    }
+    const long G = std::min<long>(nt, 1024);
+    hipLaunchKernelGGL(stem_fwd_kernel<true>, dim3((unsigned)G), dim3(256), 0, STRM(stream), p);
+    return check_launch("yolo_conv_stem7_fwd_f32");
 }

@@ -114,6 +114,8 @@ _SIGS = {
     "yolo_wgrad_slab_floats": [ctypes.POINTER(WgradDesc), ctypes.POINTER(ctypes.c_long)],
     "yolo_conv_stem7_fwd": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_long, c_int, c_float, c_int, c_void_p, c_long, c_int, c_int, c_void_p, c_long,
                             c_int, c_int, c_void_p],
+    "yolo_conv_stem7_fwd_f32": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_int, c_void_p, c_long, c_int, c_int, c_void_p, c_long, c_int, c_int,
+                                c_void_p],
     "yolo_wgrad_stem7": [c_void_p, c_void_p, c_int, c_int, c_int, c_long, c_int, c_long, c_int, c_int, c_void_p, c_void_p, c_void_p, c_long, c_void_p],
     "yolo_wgrad_stem7_pooled": [c_void_p, c_void_p, c_int, c_int, c_int, c_long, c_int, c_long, c_int, c_int, c_void_p, c_long, c_int, c_int, c_float, c_void_p,
                                 c_void_p, c_void_p, c_long, c_void_p],

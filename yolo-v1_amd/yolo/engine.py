@@ -55,6 +55,7 @@ WGRAD_SLABS = False  # pipelined weight-gradient kernel: partial tiles stored as
                      # while the atomics' traffic overlaps them.  Off by default; switch on for reproducible training runs.
 WGRAD_PIPE = True  # weight gradient of the big deep 3x3 layers through wgrad_pipe.hip (yolo_wgrad_desc.variant = 5)
 FC_NORM_IN_WGRAD = 1 << 26   # Linear layers with at least this many weights: yolo_wgrad also sums the squares of the gradient it stores
+STEM_F32_INPUT = True  # inference: the stem kernel reads the NCHW fp32 input itself (no separate layout pass)
 FLATTEN_FREE = True  # inference: conv -> nn.Flatten -> Linear without the flatten pass (dense NHWC conv output + K-permuted weight panels)
 POOL_CODES = True  # training: a fused conv + pool stores the pooled map and 2-bit arg-max codes, not the un-pooled activation
 FUSE_POOL = True   # inference: fold MaxPool2d(2,2) into the preceding conv's epilogue where the geometry allows
@@ -841,6 +842,7 @@ class Plan:
         N = x.shape[0]
         dev = x.device
         x = x.detach()
+        stem_f32 = False
         if u8_size is not None:
             from . import preprocess as _pp
             key, ws = self._workspace(N, (N, 3, u8_size[0], u8_size[1]), dev, train)
@@ -857,7 +859,15 @@ class Plan:
             key, ws = self._workspace(N, x.shape, dev, train)
             self._pack_all(train)
             a = ws["in"]
-            if a.C == 4 and a.halo == 3:
+            L0 = self.layers[0]
+            # inference: the stem kernel reads the caller's NCHW fp32 batch itself (the patch is converted on its way into LDS); training
+            # keeps the NHWC4 copy, which the stem's weight gradient reads
+            stem_f32 = (not train and STEM_F32_INPUT and STEM_KERNEL and a.C == 4 and a.halo == 3 and L0.kind == "conv" and L0.first and L0.Cout == 64
+                        and L0.Hout % 8 == 0 and L0.Wout % 16 == 0 and 2 * L0.Hout == x.shape[2] and 2 * L0.Wout == x.shape[3]
+                        and ws["acts"][0].C == 64 and L0.bias.dtype == torch.float32)      # = the conditions of the stem-kernel branch below
+            if stem_f32:
+                pass
+            elif a.C == 4 and a.halo == 3:
                 check(L_.yolo_nchw_f32_to_nhwc_bf16(ptr(x), N, x.shape[1], x.shape[2], x.shape[3], a.p, 4, 3, 3, st), "nchw->nhwc4")
             else:
                 check(L_.yolo_nchw_f32_to_nhwc_bf16(ptr(x), N, x.shape[1], x.shape[2], x.shape[3], a.p, a.C, 1, 1, st), "nchw->nhwc")
@@ -894,7 +904,11 @@ class Plan:
                     dst = ws["acts"][li + 1] if dual else nxt
                     codes = self._codes(ws, li, dst) if (dual and codes_mode) else None
                     with _timed(f"conv{li}" + ("+pool" if (fuse or dual) else ""), "stem", 2.0 * N * L.Hout * L.Wout * L.Cout * L.Cin * L.K * L.K):
-                        if codes is not None:       # pooled map + arg-max codes: the 411 MB un-pooled activation (batch 64) is never written
+                        if stem_f32 and li == 0:
+                            check(L_.yolo_conv_stem7_fwd_f32(ptr(x), ptr(wf), ptr(b), N, x.shape[2], x.shape[3], self.SLOPE if L.lrelu else 1.0,
+                                                             1 if fuse else 0, dst.p, dst.img_stride, dst.row_stride, dst.interior_off(), None, 0, 0, 0, st),
+                                  "conv_stem7_fwd_f32")
+                        elif codes is not None:       # pooled map + arg-max codes: the 411 MB un-pooled activation (batch 64) is never written
                             check(L_.yolo_conv_stem7_fwd(cur.p, ptr(wf), ptr(b), N, L.Hout, L.Wout, cur.img_stride, cur.row_stride,
                                                          self.SLOPE if L.lrelu else 1.0, 3, dst.p, dst.img_stride, dst.row_stride,
                                                          dst.interior_off(), ptr(codes), 0, 0, 0, st), "conv_stem7_fwd")
