@@ -201,7 +201,9 @@ def test_resnet_yolo_training_step_runs_and_learns():
         assert all(p.grad is not None for p in model.backbone.parameters())
         opt.step()
         losses.append(float(loss.detach()))
-    assert all(l == l for l in losses) and losses[-1] < losses[0], losses
+    # the first three losses repeat run to run (13.1, 10.8, 7.4); from then on the trajectory of this random-init network is chaotic
+    # (fp32 atomics in the weight gradients are enough to move step 5 anywhere between 3.8 and 14.8), so the check is on the early steps
+    assert all(l == l and l < 1e4 for l in losses) and losses[2] < 0.8 * losses[0] and min(losses) < 0.7 * losses[0], losses
     # two forwards before a backward would share activation buffers: refused loudly, not computed wrongly
     l1, _ = crit(model(x), t)
     l2, _ = crit(model(x), t)
