@@ -223,7 +223,7 @@ def main():
         crit = YOLOLoss()
         from yolo.optim import Adam
         opt = Adam(model.parameters(), lr=1e-4, weight_decay=5e-4, max_grad_norm=10.0)  # clip_grad_norm_(10) + Adam fused
-        opt.attach_plan(model.hip_plan(), overlap=True)   # Adam also refreshes the bf16 operands of the Linear layers
+        opt.attach_plan(model.hip_plan())   # Adam also refreshes the bf16 operands of the Linear layers
         # data parallel: gradient arena + all-reduce overlapped with the backward pass (FC1's 822 MB first)
         ar = make_grad_reducer(model, dev) if (use_dist and world > 1) else None      # the reducer the shipped training loop uses (nothing to reduce in a world of one)
 

@@ -20,7 +20,7 @@ x = torch.randn(64, 3, 448, 448, device=dev)
 tgt = torch.from_numpy(synth.synth_targets(64, seed=1)).to(dev)
 crit = YOLOLoss()
 opt = Adam(model.parameters(), lr=1e-4, weight_decay=5e-4, max_grad_norm=10.0)
-opt.attach_plan(model.head.hip_plan() if resnet else model.hip_plan(), overlap=True)
+opt.attach_plan(model.head.hip_plan() if resnet else model.hip_plan(), overlap=os.environ.get("OVERLAP", "0") == "1")
 
 
 def step():

@@ -13,6 +13,7 @@ from __future__ import annotations
 import torch
 
 import ctypes
+import os
 
 from . import _hip
 from ._hip import AdamTensor, check, lib, ptr, stream
@@ -20,7 +21,7 @@ from ._hip import AdamTensor, check, lib, ptr, stream
 
 BG_CUS = 64        # CUs the background update of the Linear layers holds (yolo_adam_step_multi_bg): a CU streams ~42 GB/s whatever it keeps in flight,
                    # so the pass runs at 2.6 TB/s there (2.4 ms) -- under the conv stack of the next forward; 24 CUs: too slow (step 13.9 ms), 96: same as 64
-OVERLAP = True     # attach_plan(overlap=True) takes effect (switch for in-process A/B runs)
+OVERLAP = os.environ.get("YOLO_ADAM_OVERLAP", "1") != "0"     # attach_plan(overlap=True) takes effect (switch for A/B runs)
 
 
 def _f32c(g: torch.Tensor) -> torch.Tensor:
@@ -194,7 +195,7 @@ class Adam(torch.optim.Optimizer):
         pass that updates their fp32 masters (``plan``: ``model.hip_plan()``).
 
         ``overlap``: update the Linear layers as a background pass on a second stream, beside the next forward's conv stack (same
-        floats; see ``synchronize`` for what then has to wait).  The training loop and bench.py switch it on."""
+        floats; see ``synchronize`` for what then has to wait).  Opt-in: worth <= 1 % of a step on this model."""
         for p, shadow, fresh in plan.bf16_shadows():
             self.bf16_shadow[id(p)] = (shadow, fresh)
             if overlap:
