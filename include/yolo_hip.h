@@ -157,7 +157,10 @@ typedef struct yolo_igemm_desc {
                                two-phase schedule (8 waves), 14: 256 x 208 x 32 staggered with an uneven 7 / 6 column
                                split between the wave groups (see tile_px), 15: the same tile with the register-pipelined
                                one-barrier loop (even number >= 4 of 32-deep K steps per split; no pool2 / bn_stats /
-                               atomics), 7-10: BK = 32 variants of 64x128  (tuning / tests;
+                               atomics), 7-10: BK = 32 variants of 64x128, 19: streaming 1x1 convolution of the thin-K pointwise
+                               layers (stride-1 1x1, tap_len 64 / 128 / 256, Cout % 64 == 0, bf16 out, N*Ho*Wo % 16 == 0: the weight
+                               panel sits in LDS, every wave walks 16-pixel groups with the next group's activation fragments and
+                               the residual vectors in flight; igemm_stream.hip)  (tuning / tests;
                                a caller that wants the best plan times them per problem, as engine.igemm_call does) */
     int64_t px_begin, px_end; /* compute only output pixels [px_begin, px_end) of the flattened (n, oy, ox) index
                                (0, 0 = all).  Lets a caller run the bulk of a layer with a large tile in whole

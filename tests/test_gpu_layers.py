@@ -576,3 +576,54 @@ def test_pool_fused_into_the_pipelined_tiles(W, cin, cout):
     assert torch.equal(ya, yb) and torch.equal(gxa, gxb)
     for a, b in zip(ga, gb):
         torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-7)      # weight gradients: fp32 atomics order only
+
+
+@pytest.mark.parametrize("cin,cout,epi", [(64, 256, "add"), (256, 64, "relu"), (128, 512, "add"), (256, 128, "gate"), (64, 64, "bias"), (128, 192, "none")])
+def test_streaming_1x1_kernel(cin, cout, epi):
+    """yolo_igemm tile_hint 19 (igemm_stream.hip): thin-K pointwise conv with every epilogue it takes (bias, bias + ReLU, bias + residual
+    + ReLU as in a ResNet bottleneck, LeakyReLU' gate of a data gradient, none) against the fp32 product of the bf16 operands, and
+    against the tiled kernel (tile_hint 10) to one bf16 ulp; halo-1 buffers, 3 x 24 x 40 pixels."""
+    import ctypes
+    from yolo._hip import IgemmDesc, check, lib, ptr, stream, EPI_BIAS, EPI_BIAS_LRELU, EPI_MUL_DLRELU, EPI_NONE, EPI_BIAS_ADD_LRELU
+    from yolo.engine import Act
+    torch.manual_seed(cin + cout)
+    dev = torch.device("cuda")
+    N, H, W = 3, 24, 40
+    x = Act(N, H, W, cin, 1, dev)
+    x.interior().copy_(torch.randn(N, H, W, cin, device=dev).to(torch.bfloat16))
+    aux = Act(N, H, W, cout, 1, dev)
+    aux.interior().copy_(torch.randn(N, H, W, cout, device=dev).to(torch.bfloat16))
+    w = (torch.randn(cout, cin, device=dev) / cin ** 0.5).to(torch.bfloat16)
+    b = torch.randn(cout, device=dev)
+    code, slope = {"add": (EPI_BIAS_ADD_LRELU, 0.0), "relu": (EPI_BIAS_LRELU, 0.0), "gate": (EPI_MUL_DLRELU, 0.1), "bias": (EPI_BIAS, 1.0), "none": (EPI_NONE, 1.0)}[epi]
+    outs = {}
+    for hint in (19, 10):
+        y = Act(N, H, W, cout, 1, dev)
+        d = IgemmDesc()
+        d.N, d.Ho, d.Wo = N, H, W
+        d.in_img_stride, d.in_row_stride, d.in_px_stride, d.in_off = x.img_stride, x.row_stride, x.px_stride, x.interior_off()
+        d.stride, d.KH, d.KW, d.tap_len, d.Cout = 1, 1, 1, cin, cout
+        d.out_img_stride, d.out_row_stride, d.out_px_stride, d.out_off = y.img_stride, y.row_stride, y.px_stride, y.interior_off()
+        d.aux_img_stride, d.aux_row_stride, d.aux_px_stride, d.aux_off = aux.img_stride, aux.row_stride, aux.px_stride, aux.interior_off()
+        d.epilogue, d.slope, d.out_fp32, d.split_k, d.tile_hint, d.tile_order = code, slope, 0, 1, hint, 1
+        check(lib().yolo_igemm(ctypes.byref(d), x.p, ptr(w), ptr(b) if epi in ("add", "relu", "bias") else None,
+                               aux.p if epi in ("add", "gate") else None, y.p, stream()), f"igemm hint {hint}")
+        outs[hint] = y
+    z = torch.einsum("nhwc,oc->nhwo", x.interior().float(), w.float())
+    a = aux.interior().float()
+    if epi == "add":
+        ref = torch.relu(z + b + a)
+    elif epi == "relu":
+        ref = torch.relu(z + b)
+    elif epi == "gate":
+        ref = z * torch.where(a > 0, 1.0, 0.1)
+    elif epi == "bias":
+        ref = z + b
+    else:
+        ref = z
+    got = outs[19].interior().float()
+    _close(got.cpu(), _bf(ref.cpu()), 1.0, f"streaming 1x1 {cin}->{cout} {epi} vs fp32")
+    _close(got.cpu(), outs[10].interior().float().cpu(), 1.0, f"streaming 1x1 {cin}->{cout} {epi} vs tile_hint 10")
+    halo = outs[19].view().clone()
+    halo[:, 1: 1 + H, 1: 1 + W, :] = 0
+    assert not bool(halo.any()), "the halo must stay zero"

@@ -86,5 +86,7 @@ __device__ __forceinline__ void wait_vmcnt()
 
 // igemm_pipe.hip: the register-pipelined one-barrier kernels (tile_hint 15 .. 18); `splits` as for the other configurations
 int igemm_pipe_launch(const IgemmParams &p, int hint, int splits, hipStream_t s);
+// igemm_stream.hip: streaming 1x1 convolution of the thin-K pointwise layers (tile_hint 19)
+int igemm_stream_launch(const IgemmParams &p, int splits, hipStream_t s);
 
 }  // namespace yolo
