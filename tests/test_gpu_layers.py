@@ -578,8 +578,9 @@ def test_pool_fused_into_the_pipelined_tiles(W, cin, cout):
         torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-7)      # weight gradients: fp32 atomics order only
 
 
-@pytest.mark.parametrize("cin,cout,epi", [(64, 256, "add"), (256, 64, "relu"), (128, 512, "add"), (256, 128, "gate"), (64, 64, "bias"), (128, 192, "none")])
-def test_streaming_1x1_kernel(cin, cout, epi):
+@pytest.mark.parametrize("cin,cout,epi,stride", [(64, 256, "add", 1), (256, 64, "relu", 1), (128, 512, "add", 1), (256, 128, "gate", 1), (64, 64, "bias", 1),
+                                                 (128, 192, "none", 1), (256, 512, "bias", 2), (64, 128, "none", 2)])
+def test_streaming_1x1_kernel(cin, cout, epi, stride):
     """yolo_igemm tile_hint 19 (igemm_stream.hip): thin-K pointwise conv with every epilogue it takes (bias, bias + ReLU, bias + residual
     + ReLU as in a ResNet bottleneck, LeakyReLU' gate of a data gradient, none) against the fp32 product of the bf16 operands, and
     against the tiled kernel (tile_hint 10) to one bf16 ulp; halo-1 buffers, 3 x 24 x 40 pixels."""
@@ -588,9 +589,9 @@ def test_streaming_1x1_kernel(cin, cout, epi):
     from yolo.engine import Act
     torch.manual_seed(cin + cout)
     dev = torch.device("cuda")
-    N, H, W = 3, 24, 40
-    x = Act(N, H, W, cin, 1, dev)
-    x.interior().copy_(torch.randn(N, H, W, cin, device=dev).to(torch.bfloat16))
+    N, H, W = 3, 24, 40                        # output grid; the input grid is stride times as large (1x1 / stride 2 = ResNet's downsample conv)
+    x = Act(N, H * stride, W * stride, cin, 1, dev)
+    x.interior().copy_(torch.randn(N, H * stride, W * stride, cin, device=dev).to(torch.bfloat16))
     aux = Act(N, H, W, cout, 1, dev)
     aux.interior().copy_(torch.randn(N, H, W, cout, device=dev).to(torch.bfloat16))
     w = (torch.randn(cout, cin, device=dev) / cin ** 0.5).to(torch.bfloat16)
@@ -602,14 +603,24 @@ def test_streaming_1x1_kernel(cin, cout, epi):
         d = IgemmDesc()
         d.N, d.Ho, d.Wo = N, H, W
         d.in_img_stride, d.in_row_stride, d.in_px_stride, d.in_off = x.img_stride, x.row_stride, x.px_stride, x.interior_off()
-        d.stride, d.KH, d.KW, d.tap_len, d.Cout = 1, 1, 1, cin, cout
+        d.stride, d.KH, d.KW, d.tap_len, d.Cout = stride, 1, 1, cin, cout
         d.out_img_stride, d.out_row_stride, d.out_px_stride, d.out_off = y.img_stride, y.row_stride, y.px_stride, y.interior_off()
         d.aux_img_stride, d.aux_row_stride, d.aux_px_stride, d.aux_off = aux.img_stride, aux.row_stride, aux.px_stride, aux.interior_off()
         d.epilogue, d.slope, d.out_fp32, d.split_k, d.tile_hint, d.tile_order = code, slope, 0, 1, hint, 1
+        acc = None
+        if epi == "none":          # BatchNorm statistics of the stored outputs (yolo_igemm_desc.bn_stats), as the ResNet trunk in training mode asks for
+            from yolo._hip import BN_ACC_REPLICAS
+            acc = torch.zeros(BN_ACC_REPLICAS * 2 * cout, dtype=torch.float64, device=dev)
+            d.bn_stats = acc.data_ptr()
         check(lib().yolo_igemm(ctypes.byref(d), x.p, ptr(w), ptr(b) if epi in ("add", "relu", "bias") else None,
                                aux.p if epi in ("add", "gate") else None, y.p, stream()), f"igemm hint {hint}")
         outs[hint] = y
-    z = torch.einsum("nhwc,oc->nhwo", x.interior().float(), w.float())
+        if acc is not None:
+            st = acc.view(BN_ACC_REPLICAS, 2, cout).sum(0).cpu()
+            stored = y.interior().double().cpu().reshape(-1, cout)
+            torch.testing.assert_close(st[0], stored.sum(0), rtol=1e-5, atol=1e-3)
+            torch.testing.assert_close(st[1], stored.pow(2).sum(0), rtol=1e-5, atol=1e-3)
+    z = torch.einsum("nhwc,oc->nhwo", x.interior()[:, ::stride, ::stride, :].float(), w.float())
     a = aux.interior().float()
     if epi == "add":
         ref = torch.relu(z + b + a)

@@ -18,8 +18,10 @@ constexpr int NW = 4, NTHR = NW * 64;
 constexpr int EP_BYTES = 16 * 64 * 4;           // wave-private epilogue patch: 16 px x 64 co fp32
 }  // namespace is
 
-// TCO: channels per workgroup (64, 128 or 256); KS = K / 32 (2, 4 or 8)
-template <int TCO, int KS>
+// TCO: channels per workgroup (64, 128 or 256); KS = K / 32 (2, 4 or 8); STATS: BatchNorm's per-channel sum / sum of squares of the
+// stored (bf16-rounded) outputs as well (yolo_igemm_desc.bn_stats, epilogue NONE): in the epilogue patch lane l reads channel l of
+// the 16 pixels and keeps the two sums in registers for the wave's whole pixel stream; one fp64 atomic pair per channel and wave
+template <int TCO, int KS, bool STATS>
 __global__ void __launch_bounds__(is::NTHR, 2) igemm_stream_kernel(const IgemmParams p)
 {
     using namespace is;
@@ -56,7 +58,7 @@ __global__ void __launch_bounds__(is::NTHR, 2) igemm_stream_kernel(const IgemmPa
         const int n = (int)(mu / (unsigned)p.HoWo);
         const int rem = (int)(mu - (unsigned)n * (unsigned)p.HoWo);
         const int oy = (int)((unsigned)rem / (unsigned)p.Wo), ox = rem - oy * p.Wo;
-        in_o = (long)n * p.in_img_stride + (long)oy * p.in_row_stride + (long)ox * p.in_px_stride + p.in_off;
+        in_o = (long)n * p.in_img_stride + (long)(oy * p.stride) * p.in_row_stride + (long)(ox * p.stride) * p.in_px_stride + p.in_off;
         out_o = (long)n * p.out_img_stride + (long)oy * p.out_row_stride + (long)ox * p.out_px_stride + p.out_off;
         aux_o = (long)n * p.aux_img_stride + (long)oy * p.aux_row_stride + (long)ox * p.aux_px_stride + p.aux_off;
     };
@@ -70,6 +72,9 @@ __global__ void __launch_bounds__(is::NTHR, 2) igemm_stream_kernel(const IgemmPa
     long g = (long)wg * NW + wave;
     const long gstep = (long)nwg * NW;
     bf16x8 bcur[KS], bnxt[KS];
+    float ssum[TCO / 64], ssq[TCO / 64];
+#pragma unroll
+    for (int c = 0; c < TCO / 64; ++c) ssum[c] = ssq[c] = 0.0f;
     if (g < ngroups) load_b(g, bcur);
     for (; g < ngroups; g += gstep) {
         if (g + gstep < ngroups) load_b(g + gstep, bnxt);
@@ -102,6 +107,14 @@ __global__ void __launch_bounds__(is::NTHR, 2) igemm_stream_kernel(const IgemmPa
 #pragma unroll
             for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4 *>(ep + px * 64 + i * 16 + 4 * kg) = acc[c * 4 + i];
             // (same wave writes and reads: LDS operations of a wave complete in order)
+            if constexpr (STATS) {
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    const float r = __uint_as_float((unsigned)f32_to_bf16(ep[q * 64 + lane]) << 16);     // the value as stored
+                    ssum[c] += r;
+                    ssq[c] += r * r;
+                }
+            }
             float v[16];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
@@ -145,17 +158,25 @@ __global__ void __launch_bounds__(is::NTHR, 2) igemm_stream_kernel(const IgemmPa
 #pragma unroll
         for (int s = 0; s < KS; ++s) bcur[s] = bnxt[s];
     }
+    if constexpr (STATS) {
+        double *rep = p.stats + (size_t)(blockIdx.x % YOLO_BN_ACC_REPLICAS) * 2 * p.Cout;
+#pragma unroll
+        for (int c = 0; c < TCO / 64; ++c) {
+            atomicAdd(rep + co0 + c * 64 + lane, (double)ssum[c]);
+            atomicAdd(rep + p.Cout + co0 + c * 64 + lane, (double)ssq[c]);
+        }
+    }
 }
 
-template <int TCO, int KS>
-static int stream_launch(const IgemmParams &p, hipStream_t s)
+template <int TCO, int KS, bool STATS>
+static int stream_launch_impl(const IgemmParams &p, hipStream_t s)
 {
     constexpr int LDS = TCO * KS * 32 * 2 + is::NW * is::EP_BYTES;
     static bool attr_done[64] = {};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
     if (!attr_done[dev]) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&igemm_stream_kernel<TCO, KS>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&igemm_stream_kernel<TCO, KS, STATS>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         if (e != hipSuccess) return fail((int)e, "yolo_igemm: hipFuncSetAttribute(%d B LDS): %s", LDS, hipGetErrorString(e));
         attr_done[dev] = true;
     }
@@ -167,17 +188,23 @@ static int stream_launch(const IgemmParams &p, hipStream_t s)
     const long need = ((p.M >> 4) + is::NW - 1) / is::NW;
     if (nwg > need) nwg = need;
     nwg = (std::max<long>(nwg, 1) + 7) / 8 * 8;
-    hipLaunchKernelGGL((igemm_stream_kernel<TCO, KS>), dim3((unsigned)(nwg * q.n_co_tiles)), dim3(is::NTHR), LDS, s, q);
+    hipLaunchKernelGGL((igemm_stream_kernel<TCO, KS, STATS>), dim3((unsigned)(nwg * q.n_co_tiles)), dim3(is::NTHR), LDS, s, q);
     return check_launch("yolo_igemm (streaming 1x1)");
+}
+
+template <int TCO, int KS>
+static int stream_launch(const IgemmParams &p, hipStream_t s)
+{
+    return p.stats ? stream_launch_impl<TCO, KS, true>(p, s) : stream_launch_impl<TCO, KS, false>(p, s);
 }
 
 int igemm_stream_launch(const IgemmParams &p, int splits, hipStream_t s)
 {
     const int K = p.tap_len;
-    if (p.KH != 1 || p.KW != 1 || p.stride != 1 || (K != 64 && K != 128 && K != 256) || (p.Cout % 64) || p.out_fp32 || p.pool || p.stats || p.w_blocked || splits > 1 ||
-        p.slab_stride || p.px_begin || (p.M & 15) || p.M >= (1L << 31))
-        return fail(YOLO_E_UNSUPPORTED, "yolo_igemm: tile_hint 19 (streaming 1x1) takes stride-1 1x1 convs with 64 / 128 / 256 input channels, Cout %% 64 == 0, "
-                                        "bf16 output, M %% 16 == 0, no pool / split-K / statistics / pixel range");
+    if (p.KH != 1 || p.KW != 1 || p.stride < 1 || (K != 64 && K != 128 && K != 256) || (p.Cout % 64) || p.out_fp32 || p.pool || p.w_blocked || splits > 1 ||
+        p.slab_stride || p.px_begin || (p.M & 15) || p.M >= (1L << 31) || (p.stats && p.epilogue != YOLO_EPI_NONE))
+        return fail(YOLO_E_UNSUPPORTED, "yolo_igemm: tile_hint 19 (streaming 1x1) takes 1x1 convs with 64 / 128 / 256 input channels, Cout %% 64 == 0, "
+                                        "bf16 output, M %% 16 == 0, no pool / split-K / pixel range; bn_stats with epilogue NONE only");
     if ((p.in_px_stride & 7) || (p.in_row_stride & 7) || (p.in_img_stride & 7) || (p.in_off & 7) || (p.out_px_stride & 7) || (p.out_row_stride & 7) ||
         (p.out_img_stride & 7) || (p.out_off & 7) || (p.aux_px_stride & 7) || (p.aux_row_stride & 7) || (p.aux_img_stride & 7) || (p.aux_off & 7))
         return fail(YOLO_E_UNSUPPORTED, "yolo_igemm: tile_hint 19 needs strides and offsets in multiples of 8 elements");

@@ -254,8 +254,8 @@ def _run_plan_igemm(L_, d: IgemmDesc, plan, inp, w, bias, aux, out, st, what):
             plan = ("skew", 14) + tuple(plan[2:])
         elif isinstance(plan[0], int) and plan[0] in (15, 16, 17, 18):
             plan = (14, plan[1])
-        elif isinstance(plan[0], int) and plan[0] == 19:
-            plan = (10, plan[1])           # the streaming 1x1 kernel has none either
+        elif isinstance(plan[0], int) and plan[0] == 19 and d.epilogue != EPI_NONE:
+            plan = (10, plan[1])           # the streaming 1x1 kernel accumulates statistics of raw conv outputs only
     d.tile_px, d.px_begin, d.px_end, d.skew_phases, d.skew_step = 0, 0, 0, 0, 0
     if plan[0] in ("splitk", "slabs"):
         # few-pixel deep-K layer: S workgroups per output tile into a dense fp32 scratch (atomics, or one slab per split),
@@ -335,8 +335,7 @@ def _tune(L_, d: IgemmDesc, inp, w, bias, aux, out, st, what):
         cands = []                # the 8 x 16-patch pooled epilogue does not tile this map: pipelined 224-pixel tiles only
     if d.KH == 1 and d.KW == 1 and d.tap_len <= 256 and not d.pool2:
         cands.append(10)      # thin-K 1x1 layers stream: 64x128x32, 28 KB of LDS, five workgroups per CU
-        if (d.stride == 1 and d.tap_len in (64, 128, 256) and d.Cout % 64 == 0 and (d.N * d.Ho * d.Wo) % 16 == 0 and not d.out_fp32 and not d.bn_stats
-                and d.split_k <= 1):
+        if d.tap_len in (64, 128, 256) and d.Cout % 64 == 0 and (d.N * d.Ho * d.Wo) % 16 == 0 and not d.out_fp32 and d.split_k <= 1:
             cands.append(19)  # ... or the streaming 1x1 kernel (igemm_stream.hip): weight panel in LDS, activations straight into MFMA fragments
     orders = (1, 2) if (d.Cout * d.KH * d.KW * d.tap_len * 2 > (4 << 20) and d.Cout >= 1024) else (1,)
     for c in cands:
