@@ -165,7 +165,7 @@ def _flush_caches(dev):
 
 # tile edge (co, px slots) of the configurations the tuner may combine
 _TILE = {1: (128, 128), 3: (128, 64), 4: (64, 128), 5: (128, 128), 10: (64, 128), 11: (256, 128), 12: (256, 256), 13: (256, 128), 14: (256, 208),
-         15: (256, 208), 16: (256, 224), 17: (128, 208), 18: (128, 224)}
+         15: (256, 208), 16: (256, 224), 17: (128, 208), 18: (128, 224), 19: (64, 16)}      # (19: the streaming 1x1 kernel works in 16-pixel groups)
 _TAIL_CANDIDATES = (5, 3, 4)
 # (workgroup slots of the chip, relative time of one tile) per configuration, for _default_plan: 8-wave configurations run
 # one workgroup per CU, the 4-wave ones two; times are relative to a 256x256 tile and follow the measured in-tile rates
