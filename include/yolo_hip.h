@@ -158,7 +158,7 @@ typedef struct yolo_igemm_desc {
                                split between the wave groups (see tile_px), 15: the same tile with the register-pipelined
                                one-barrier loop (even number >= 4 of 32-deep K steps per split; no pool2 / bn_stats /
                                atomics), 7-10: BK = 32 variants of 64x128, 19: streaming 1x1 convolution of the thin-K pointwise
-                               layers (stride-1 1x1, tap_len 64 / 128 / 256, Cout % 64 == 0, bf16 out, N*Ho*Wo % 16 == 0: the weight
+                               layers (1x1, tap_len 64 / 128 / 192 / 256 / 512, Cout % 64 == 0, bf16 out, N*Ho*Wo % 16 == 0: the weight
                                panel sits in LDS, every wave walks 16-pixel groups with the next group's activation fragments and
                                the residual vectors in flight; igemm_stream.hip)  (tuning / tests;
                                a caller that wants the best plan times them per problem, as engine.igemm_call does) */

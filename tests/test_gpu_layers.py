@@ -579,7 +579,8 @@ def test_pool_fused_into_the_pipelined_tiles(W, cin, cout):
 
 
 @pytest.mark.parametrize("cin,cout,epi,stride", [(64, 256, "add", 1), (256, 64, "relu", 1), (128, 512, "add", 1), (256, 128, "gate", 1), (64, 64, "bias", 1),
-                                                 (128, 192, "none", 1), (256, 512, "bias", 2), (64, 128, "none", 2)])
+                                                 (128, 192, "none", 1), (256, 512, "bias", 2), (64, 128, "none", 2), (512, 256, "relu", 1), (192, 128, "gate", 1),
+                                                 (512, 64, "none", 1)])
 def test_streaming_1x1_kernel(cin, cout, epi, stride):
     """yolo_igemm tile_hint 19 (igemm_stream.hip): thin-K pointwise conv with every epilogue it takes (bias, bias + ReLU, bias + residual
     + ReLU as in a ResNet bottleneck, LeakyReLU' gate of a data gradient, none) against the fp32 product of the bf16 operands, and

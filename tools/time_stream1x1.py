@@ -11,7 +11,9 @@ from yolo.engine import Act
 dev = torch.device("cuda")
 N = 64
 for (cin, cout, hw, res) in [(64, 256, 112, True), (256, 64, 112, False), (64, 64, 112, False), (64, 256, 112, False), (256, 128, 112, False),
-                             (128, 512, 56, True), (256, 1024, 28, True), (256, 512, 56, False)]:
+                             (128, 512, 56, True), (256, 1024, 28, True), (256, 512, 56, False),
+                             # YOLOv1's pointwise layers
+                             (192, 128, 56, False), (256, 256, 56, False), (512, 256, 28, False), (512, 512, 28, False)]:
     x = Act(N, hw, hw, cin, 1, dev); x.t.normal_()
     aux = Act(N, hw, hw, cout, 1, dev); aux.t.normal_()
     y = Act(N, hw, hw, cout, 1, dev)

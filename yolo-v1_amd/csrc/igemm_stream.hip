@@ -18,7 +18,7 @@ constexpr int NW = 4, NTHR = NW * 64;
 constexpr int EP_BYTES = 16 * 64 * 4;           // wave-private epilogue patch: 16 px x 64 co fp32
 }  // namespace is
 
-// TCO: channels per workgroup (64, 128 or 256); KS = K / 32 (2, 4 or 8); STATS: BatchNorm's per-channel sum / sum of squares of the
+// TCO: channels per workgroup (64, 128 or 256); KS = K / 32 (2, 4, 6, 8 or 16); STATS: BatchNorm's per-channel sum / sum of squares of the
 // stored (bf16-rounded) outputs as well (yolo_igemm_desc.bn_stats, epilogue NONE): in the epilogue patch lane l reads channel l of
 // the 16 pixels and keeps the two sums in registers for the wave's whole pixel stream; one fp64 atomic pair per channel and wave
 template <int TCO, int KS, bool STATS>
@@ -71,13 +71,20 @@ __global__ void __launch_bounds__(is::NTHR, 2) igemm_stream_kernel(const IgemmPa
 
     long g = (long)wg * NW + wave;
     const long gstep = (long)nwg * NW;
-    bf16x8 bcur[KS], bnxt[KS];
+    // K <= 256: the next group's fragments are prefetched into a second register set; deeper K (512): one set of 64 registers, the
+    // 16 loads of a group and the other waves of the CU cover the latency
+    constexpr bool PREFETCH = KS <= 8;
+    bf16x8 bcur[KS], bnxt[PREFETCH ? KS : 1];
     float ssum[TCO / 64], ssq[TCO / 64];
 #pragma unroll
     for (int c = 0; c < TCO / 64; ++c) ssum[c] = ssq[c] = 0.0f;
-    if (g < ngroups) load_b(g, bcur);
+    if (PREFETCH && g < ngroups) load_b(g, bcur);
     for (; g < ngroups; g += gstep) {
-        if (g + gstep < ngroups) load_b(g + gstep, bnxt);
+        if constexpr (PREFETCH) {
+            if (g + gstep < ngroups) load_b(g + gstep, bnxt);
+        } else {
+            load_b(g, bcur);
+        }
         // output / residual addresses of this lane's epilogue pixel; the residual vectors of all chunks are fetched now
         long io, oo, ao;
         pixel(g * 16 + epx, io, oo, ao);
@@ -155,8 +162,10 @@ __global__ void __launch_bounds__(is::NTHR, 2) igemm_stream_kernel(const IgemmPa
             *reinterpret_cast<uint4 *>(o) = o0;
             *reinterpret_cast<uint4 *>(o + 8) = o1;
         }
+        if constexpr (PREFETCH) {
 #pragma unroll
-        for (int s = 0; s < KS; ++s) bcur[s] = bnxt[s];
+            for (int s = 0; s < KS; ++s) bcur[s] = bnxt[s];
+        }
     }
     if constexpr (STATS) {
         double *rep = p.stats + (size_t)(blockIdx.x % YOLO_BN_ACC_REPLICAS) * 2 * p.Cout;
@@ -201,19 +210,21 @@ static int stream_launch(const IgemmParams &p, hipStream_t s)
 int igemm_stream_launch(const IgemmParams &p, int splits, hipStream_t s)
 {
     const int K = p.tap_len;
-    if (p.KH != 1 || p.KW != 1 || p.stride < 1 || (K != 64 && K != 128 && K != 256) || (p.Cout % 64) || p.out_fp32 || p.pool || p.w_blocked || splits > 1 ||
+    if (p.KH != 1 || p.KW != 1 || p.stride < 1 || (K != 64 && K != 128 && K != 192 && K != 256 && K != 512) || (p.Cout % 64) || p.out_fp32 || p.pool || p.w_blocked || splits > 1 ||
         p.slab_stride || p.px_begin || (p.M & 15) || p.M >= (1L << 31) || (p.stats && p.epilogue != YOLO_EPI_NONE))
-        return fail(YOLO_E_UNSUPPORTED, "yolo_igemm: tile_hint 19 (streaming 1x1) takes 1x1 convs with 64 / 128 / 256 input channels, Cout %% 64 == 0, "
+        return fail(YOLO_E_UNSUPPORTED, "yolo_igemm: tile_hint 19 (streaming 1x1) takes 1x1 convs with 64 / 128 / 192 / 256 / 512 input channels, Cout %% 64 == 0, "
                                         "bf16 output, M %% 16 == 0, no pool / split-K / pixel range; bn_stats with epilogue NONE only");
     if ((p.in_px_stride & 7) || (p.in_row_stride & 7) || (p.in_img_stride & 7) || (p.in_off & 7) || (p.out_px_stride & 7) || (p.out_row_stride & 7) ||
         (p.out_img_stride & 7) || (p.out_off & 7) || (p.aux_px_stride & 7) || (p.aux_row_stride & 7) || (p.aux_img_stride & 7) || (p.aux_off & 7))
         return fail(YOLO_E_UNSUPPORTED, "yolo_igemm: tile_hint 19 needs strides and offsets in multiples of 8 elements");
-    // channels per workgroup: the panel must fit 64 KB of LDS (K = 256: 128 channels)
-    const int tco = (p.Cout % 256 == 0 && K <= 128) ? 256 : (p.Cout % 128 == 0 ? 128 : 64);
+    // channels per workgroup: the panel must fit 64 KB of LDS (K = 192 / 256: 128 channels, K = 512: 64)
+    const int tco = (p.Cout % 256 == 0 && K <= 128) ? 256 : ((p.Cout % 128 == 0 && K <= 256) ? 128 : 64);
     switch (K) {
     case 64: return tco == 256 ? stream_launch<256, 2>(p, s) : (tco == 128 ? stream_launch<128, 2>(p, s) : stream_launch<64, 2>(p, s));
     case 128: return tco == 256 ? stream_launch<256, 4>(p, s) : (tco == 128 ? stream_launch<128, 4>(p, s) : stream_launch<64, 4>(p, s));
-    default: return tco == 128 ? stream_launch<128, 8>(p, s) : stream_launch<64, 8>(p, s);
+    case 192: return tco == 128 ? stream_launch<128, 6>(p, s) : stream_launch<64, 6>(p, s);
+    case 256: return tco == 128 ? stream_launch<128, 8>(p, s) : stream_launch<64, 8>(p, s);
+    default: return stream_launch<64, 16>(p, s);
     }
 }
 

@@ -335,7 +335,8 @@ def _tune(L_, d: IgemmDesc, inp, w, bias, aux, out, st, what):
         cands = []                # the 8 x 16-patch pooled epilogue does not tile this map: pipelined 224-pixel tiles only
     if d.KH == 1 and d.KW == 1 and d.tap_len <= 256 and not d.pool2:
         cands.append(10)      # thin-K 1x1 layers stream: 64x128x32, 28 KB of LDS, five workgroups per CU
-        if d.tap_len in (64, 128, 256) and d.Cout % 64 == 0 and (d.N * d.Ho * d.Wo) % 16 == 0 and not d.out_fp32 and d.split_k <= 1:
+    if d.KH == 1 and d.KW == 1 and not d.pool2:
+        if d.tap_len in (64, 128, 192, 256, 512) and d.Cout % 64 == 0 and (d.N * d.Ho * d.Wo) % 16 == 0 and not d.out_fp32 and d.split_k <= 1:
             cands.append(19)  # ... or the streaming 1x1 kernel (igemm_stream.hip): weight panel in LDS, activations straight into MFMA fragments
     orders = (1, 2) if (d.Cout * d.KH * d.KW * d.tap_len * 2 > (4 << 20) and d.Cout >= 1024) else (1,)
     for c in cands:
