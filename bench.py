@@ -78,7 +78,7 @@ def kernel_rooflines(fn, reps=2):
         d[1] += flops / reps
         d[2] += 1
     engine.TIMERS = None
-    names = {"igemm": "igemm_kernel / igemm_pipe_kernel (implicit GEMM: conv / Linear forward and data gradient)",
+    names = {"igemm": "igemm_kernel / igemm_pipe_kernel / igemm_stream_kernel (implicit GEMM: conv / Linear forward and data gradient)",
              "wgrad": "wgrad_kernel / wgrad_pipe_kernel (weight gradient, ds_read_b64_tr_b16 operands; each launch timed alone -- the step itself runs them on a second stream beside the data gradients)", "stem": "stem_fwd_kernel (7x7/s2 stem)"}
     out = {}
     for kern, (ms, fl, n) in agg.items():
@@ -205,7 +205,7 @@ def main():
         tpath = os.path.join(ROOT, "profiles", tnames[-1]) if tnames else ""
         if tnames:
             traffic = round(json.load(open(tpath))["hbm_bytes_per_launch"])
-        roof = {"kernel": "igemm_kernel / igemm_pipe_kernel (implicit-GEMM conv/FC, v_mfma_f32_16x16x32_bf16)", "bound": "mfma",
+        roof = {"kernel": "igemm_kernel / igemm_pipe_kernel / igemm_stream_kernel (implicit-GEMM conv/FC, v_mfma_f32_16x16x32_bf16)", "bound": "mfma",
                 "achieved": round(ach, 2), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4),
                 "traffic": traffic, "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE + WRITE_SIZE with the guide's gfx950 corrections, profiles/" + (os.path.basename(tpath) if tnames else "-") + ")",
                 "launches_per_step": n_launch, "avg_launch_ms": round(ig_ms / n_launch, 4),
