@@ -95,39 +95,44 @@ __global__ void __launch_bounds__(256, 2) stem_fwd_kernel(const StemFwdParams p)
         if (wave < 3) STEM_GLDS16(xb + x_off[1], sb + (4 + wave) * 1024);
     };
 
-    // F32IN: this thread's (at most) two slots = 2 x 2 pixels x 3 planes, loaded into registers one tile ahead and written to LDS as
-    // NHWC4 bf16 (channel 3 = 0) after the MFMA phase of the current tile; pixels outside the image are the conv's zero padding
-    float xr[2][6];
+    // F32IN: the 21 x 40-pixel patch of a tile = 21 rows x 11 aligned float4 x 3 planes (the patch starts one pixel behind a multiple of
+    // four; W % 4 == 0, so a quad lies entirely inside or outside the image).  A thread takes up to three (row, plane, quad) items:
+    // loaded into registers one tile ahead, written to LDS as the bf16 channel c of four NHWC4 pixels after the MFMA phase of the current
+    // tile (channel 3 is zeroed once); pixels outside the image are the conv's zero padding.
+    constexpr int F32_ITEMS = SF_PH * 3 * 11, F32_PER_THREAD = (F32_ITEMS + 255) / 256;
+    float4 xr[F32_PER_THREAD];
+    if constexpr (F32IN) {
+        for (int i = tid; i < SF_X_BYTES / 16; i += 256) {
+            *reinterpret_cast<uint4 *>(patchA + i * 16) = uint4{0u, 0u, 0u, 0u};
+            *reinterpret_cast<uint4 *>(patchB + i * 16) = uint4{0u, 0u, 0u, 0u};
+        }
+        __syncthreads();
+    }
     auto f32_load = [&](int tile) {
         const int tx = tile % p.tiles_x, r = tile / p.tiles_x;
         const int ty = r % p.tiles_y, n = r / p.tiles_y;
         const float *xb = p.x32 + (long)n * 3 * p.H * p.W;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            int slot = (i * 4 + wave) * 64 + lane;
-            if (slot >= SF_PH * (SF_PW / 2)) slot = SF_PH * (SF_PW / 2) - 1;
-            const int y = ty * SF_TH * 2 - 3 + slot / (SF_PW / 2), x0 = tx * SF_TW * 2 - 3 + (slot % (SF_PW / 2)) * 2;
-            const bool yin = y >= 0 && y < p.H && (i == 0 || wave < 3);
-#pragma unroll
-            for (int e = 0; e < 2; ++e) {
-                const int x = x0 + e;
-                const bool in = yin && x >= 0 && x < p.W;
-                const long o = (long)y * p.W + x;
-#pragma unroll
-                for (int c = 0; c < 3; ++c) xr[i][e * 3 + c] = in ? xb[(long)c * p.H * p.W + o] : 0.0f;
-            }
+        for (int j = 0; j < F32_PER_THREAD; ++j) {
+            const int item = j * 256 + tid;
+            const int q = item % 11, rc = item / 11, c = rc % 3, pr = rc / 3;
+            const int y = ty * SF_TH * 2 - 3 + pr, x = tx * SF_TW * 2 - 4 + 4 * q;
+            const bool in = item < F32_ITEMS && y >= 0 && y < p.H && x >= 0 && x < p.W;
+            xr[j] = in ? *reinterpret_cast<const float4 *>(xb + ((long)c * p.H + y) * p.W + x) : float4{0.0f, 0.0f, 0.0f, 0.0f};
         }
     };
     auto f32_store = [&](char *sb) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            if (i == 1 && wave >= 3) continue;
-            uint4 o;
-            o.x = (unsigned)f32_to_bf16(xr[i][0]) | ((unsigned)f32_to_bf16(xr[i][1]) << 16);
-            o.y = (unsigned)f32_to_bf16(xr[i][2]);
-            o.z = (unsigned)f32_to_bf16(xr[i][3]) | ((unsigned)f32_to_bf16(xr[i][4]) << 16);
-            o.w = (unsigned)f32_to_bf16(xr[i][5]);
-            *reinterpret_cast<uint4 *>(sb + ((i * 4 + wave) * 64 + lane) * 16) = o;
+        for (int j = 0; j < F32_PER_THREAD; ++j) {
+            const int item = j * 256 + tid;
+            if (item >= F32_ITEMS) continue;
+            const int q = item % 11, rc = item / 11, c = rc % 3, pr = rc / 3;
+            const float v[4] = {xr[j].x, xr[j].y, xr[j].z, xr[j].w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int ppx = 4 * q - 1 + e;                      // patch pixel 0 = image x = 32 tx - 3
+                if (ppx >= 0 && ppx < SF_PW) *reinterpret_cast<bf16_t *>(sb + (pr * SF_PW + ppx) * 8 + c * 2) = f32_to_bf16(v[e]);
+            }
         }
     };
 
@@ -339,6 +344,7 @@ YOLO_API int yolo_conv_stem7_fwd_f32(const float *x_nchw, const void *w_packed, 
     if (out_full && pool2 != 3 && (!pool2 || (full_row_stride & 7) || (full_img_stride & 7) || (full_off & 7) || ((uintptr_t)out_full & 15)))
         return fail(YOLO_E_ARG, "yolo_conv_stem7_fwd_f32: out_full needs pool2 = 1 and strides in multiples of 8 elements");
     if ((Ho % SF_TH) || (Wo % SF_TW)) return fail(YOLO_E_UNSUPPORTED, "yolo_conv_stem7_fwd_f32: output %dx%d is not a multiple of %dx%d", Ho, Wo, SF_TH, SF_TW);
+    if ((uintptr_t)x_nchw & 15) return fail(YOLO_E_UNSUPPORTED, "yolo_conv_stem7_fwd_f32: the input must be 16-B aligned (rows are read as float4)");
     if ((out_row_stride & 7) || (out_img_stride & 7) || (out_off & 7) || ((uintptr_t)out & 15) || ((uintptr_t)w_packed & 15))
         return fail(YOLO_E_UNSUPPORTED, "yolo_conv_stem7_fwd_f32: strides must be multiples of 8 elements and pointers 16-B aligned");
     StemFwdParams p{};
