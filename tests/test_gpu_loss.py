@@ -70,3 +70,40 @@ def test_other_shapes(ops):
     ref5, refg = O.loss_fwd_bwd(pred, tgt, S, B, C)
     np.testing.assert_allclose(out.cpu().numpy()[:5], ref5, rtol=1e-5, atol=1e-6)
     np.testing.assert_allclose(dpred.cpu().numpy(), refg, rtol=1e-6, atol=1e-8)
+
+
+def test_loss_components_are_fetched_when_read():
+    """YOLOLoss on device tensors returns LossParts: the reference's dict of five floats (loss.py:165-169), copied to the host by a side
+    stream and awaited at the first read -- equal to the eager copy; the reference's IndexError case (a target selecting a box slot
+    >= B) surfaces at that read, or at the next loss call when the dict is never read."""
+    from yolo import YOLOLoss
+    from yolo.loss import LossParts
+    rng = np.random.Generator(np.random.PCG64([7, 7]))
+    pred = torch.from_numpy(rng.normal(size=(4, 7, 7, 30)).astype(np.float32)).cuda().requires_grad_(True)
+    tgt = np.zeros((4, 7, 7, 30), np.float32)
+    tgt[0, 2, 3, 0:5] = [0.5, 0.5, 0.3, 0.4, 1.0]
+    tgt[0, 2, 3, 10 + 4] = 1.0
+    tgt = torch.from_numpy(tgt).cuda()
+    crit = YOLOLoss()
+    total, parts = crit(pred, tgt)
+    assert isinstance(parts, LossParts) and isinstance(parts, dict) and list(parts) == ["total", "coord", "conf_obj", "conf_noobj", "class"]
+    crit.eager_parts = True
+    total_e, eager = crit(pred, tgt)
+    assert type(eager) is dict and parts == eager and dict(parts.items()) == eager and parts["total"] == eager["total"]
+    assert abs(parts["total"] - float(total.detach())) <= 1e-6 * abs(float(total.detach())) and "coord" in repr(parts)
+    total.backward()                                     # the autograd side is unchanged
+    assert pred.grad is not None
+    # a target that selects slot 2 (channel 14 of the 4::5 slice, B = 2)
+    bad = torch.zeros((2, 7, 7, 30)).cuda()
+    bad[1, 1, 1, 14] = 1.0
+    crit.eager_parts = False
+    _, p1 = crit(torch.zeros((2, 7, 7, 30)).cuda(), bad)
+    with pytest.raises(RuntimeError, match="index out of bounds"):
+        p1["total"]
+    _, p2 = crit(torch.zeros((2, 7, 7, 30)).cuda(), bad)           # never read ...
+    torch.cuda.synchronize()
+    with pytest.raises(RuntimeError, match="index out of bounds"):
+        crit(pred, tgt)                                             # ... so the next call reports it
+    crit.eager_parts = True
+    with pytest.raises(RuntimeError, match="index out of bounds"):
+        crit(torch.zeros((2, 7, 7, 30)).cuda(), bad)
