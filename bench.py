@@ -223,7 +223,9 @@ def main():
         crit = YOLOLoss()
         from yolo.optim import Adam
         opt = Adam(model.parameters(), lr=1e-4, weight_decay=5e-4, max_grad_norm=10.0)  # clip_grad_norm_(10) + Adam fused
-        opt.attach_plan(model.hip_plan())   # Adam also refreshes the bf16 operands of the Linear layers
+        # Adam also refreshes the bf16 operands of the Linear layers, and updates them as a background pass on 64 CUs of a second stream
+        # beside the next forward's conv stack (the forward waits for it in front of its first Linear layer)
+        opt.attach_plan(model.hip_plan(), overlap=True)
         # data parallel: gradient arena + all-reduce overlapped with the backward pass (FC1's 822 MB first)
         ar = make_grad_reducer(model, dev) if (use_dist and world > 1) else None      # the reducer the shipped training loop uses (nothing to reduce in a world of one)
 
@@ -245,12 +247,17 @@ def main():
                 ms = e0.elapsed_time(e1)
                 print(f"train {tag:16s} {kern:14s} {ms:8.3f} ms {flops / max(ms, 1e-9) / 1e9:9.1f} TFLOP/s", file=sys.stderr)
             engine.TIMERS = None
-        troof = kernel_rooflines(step)      # on every rank: the step holds a collective when N > 1
+        def step_alone():                   # for the per-launch rooflines: no background optimizer pass of the previous step beside the kernels
+            opt.synchronize()
+            torch.cuda.synchronize()
+            step()
+
+        troof = kernel_rooflines(step_alone)      # on every rank: the step holds a collective when N > 1
         train = {"value": round(world * B * ksteps / dt_t, 1), "unit": "images/s", "ms_per_step": round(1e3 * dt_t / ksteps, 3),
                  "steps": ksteps, "global_batch": world * B,
                  "step_tflops": round(120.8e9 * world * B / (dt_t / ksteps) / 1e12, 1),
                  "roofline": troof.get("wgrad"), "roofline_igemm": troof.get("igemm"),
-                 "includes": "zero_grad, forward, YOLOLoss fwd+bwd (HIP), backward (HIP), " + ("RCCL grad all-reduce overlapped with backward, " if ar is not None else "") + "clip_grad_norm_(10), Adam(lr 1e-4, wd 5e-4)",
+                 "includes": "zero_grad, forward, YOLOLoss fwd+bwd (HIP), backward (HIP), " + ("RCCL grad all-reduce overlapped with backward, " if ar is not None else "") + "clip_grad_norm_(10), Adam(lr 1e-4, wd 5e-4; the Linear layers' update as a background pass beside the next forward)",
                  "flops_per_image": 120.8e9, "first_layer_dgrad": "skipped (input needs no gradient)"}
         model.eval()
 
