@@ -89,6 +89,10 @@ def test_loss_components_are_fetched_when_read():
     assert isinstance(parts, LossParts) and isinstance(parts, dict) and list(parts) == ["total", "coord", "conf_obj", "conf_noobj", "class"]
     crit.eager_parts = True
     total_e, eager = crit(pred, tgt)
+    _, again = crit.__class__()(pred, tgt)                # a fresh, unread LossParts: every way of copying it must see the values
+    assert dict(again) == eager and {**crit.__class__()(pred, tgt)[1]} == eager and list(crit.__class__()(pred, tgt)[1].values()) == list(eager.values())
+    import copy, json
+    assert copy.deepcopy(crit.__class__()(pred, tgt)[1]) == eager and json.loads(json.dumps(crit.__class__()(pred, tgt)[1])) == eager
     assert type(eager) is dict and parts == eager and dict(parts.items()) == eager and parts["total"] == eager["total"]
     assert abs(parts["total"] - float(total.detach())) <= 1e-6 * abs(float(total.detach())) and "coord" in repr(parts)
     total.backward()                                     # the autograd side is unchanged

@@ -332,3 +332,34 @@ def test_draw_detections_takes_the_reference_call():
     legacy = draw_detections(img, [(11, 0.9, 0.5, 0.5, 0.4, 0.4)], VOC_CLASSES)
     assert legacy.load()[60, 50] == px[60, 50]
     assert draw_detections(img, dets, box_width=1, font_size=10).size == img.size   # keyword form of the remaining parameters
+
+
+def test_loss_parts_behaves_like_the_reference_dict():
+    """yolo.loss.LossParts (the lazily fetched form of the reference's {"total": ..., ...} float dict, loss.py:165-169): every way of
+    reading or copying it sees the values, the bad-slot flag raises at the first read (fake event + host buffer: no GPU needed)."""
+    import copy
+    import json
+    import torch
+    from yolo.loss import LossParts
+
+    class Ev:
+        def synchronize(self):
+            pass
+
+        def query(self):
+            return True
+
+    def mk(flag=0.0):
+        return LossParts(Ev(), torch.tensor([5.0, 1.0, 2.0, 3.0, 4.0, flag, 0.0, 0.0]))
+
+    want = {"total": 5.0, "coord": 1.0, "conf_obj": 2.0, "conf_noobj": 3.0, "class": 4.0}
+    assert dict(mk()) == want and {**mk()} == want and list(mk().values()) == list(want.values()) and copy.deepcopy(mk()) == want
+    assert json.loads(json.dumps(mk())) == want and mk()["coord"] == 1.0 and mk().get("class") == 4.0 and list(mk()) == list(want)
+    assert len(mk()) == 5 and "total" in mk() and mk() == want and f"{mk()['total']:.1f}" == "5.0"
+    d = {}
+    d.update(mk())
+    assert d == want and sum(mk().values()) == 15.0
+    with pytest.raises(RuntimeError, match="index out of bounds"):
+        mk(1.0)["total"]
+    with pytest.raises(RuntimeError, match="index out of bounds"):
+        dict(mk(1.0))

@@ -70,6 +70,12 @@ class LossParts(dict):
     def __getitem__(self, k):
         return dict.__getitem__(self._fetch(), k)
 
+    def __iter__(self):          # (also keeps dict(parts) / {**parts} off CPython's raw-storage fast path, which would copy the placeholders)
+        return dict.__iter__(self._fetch())
+
+    def keys(self):
+        return dict.keys(self._fetch())
+
     def get(self, k, default=None):
         return dict.get(self._fetch(), k, default)
 
