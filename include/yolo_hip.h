@@ -28,7 +28,10 @@
 extern "C" {
 #endif
 
-#define YOLO_HIP_ABI_VERSION 1
+/* 2: yolo_igemm_desc gained tile_px / split_slabs, yolo_wgrad_desc gained dw_sumsq / slabs / slab_floats, the multi-tensor Adam entries
+ *    gained skip_flag, yolo_conv_stem7_dgrad is new.  A binding must refuse a library whose version differs from the header it was
+ *    written against (yolo/_hip.py does): the descriptors are passed by pointer and a shorter struct would be read past its end. */
+#define YOLO_HIP_ABI_VERSION 2
 
 #define YOLO_E_ARG (-1)         /* bad argument (null pointer, size out of range)              */
 #define YOLO_E_UNSUPPORTED (-2) /* shape not supported by the kernels (see each function)      */
@@ -420,7 +423,11 @@ int yolo_adam_step(float *p, const float *g, float *exp_avg, float *exp_avg_sq, 
 /* Multi-tensor forms: ONE launch for a whole parameter list (the reference's optimizer is torch's
  * multi-tensor `_foreach` Adam; 48 of this model's 52 tensors are too small to fill the chip alone).
  * Tables are host arrays; they are copied into the kernel arguments, YOLO_MT_MAX tensors per launch.
- * All tensors of one yolo_adam_step_multi call share `step` and the hyper-parameters. */
+ * All tensors of one yolo_adam_step_multi call share `step` and the hyper-parameters.
+ * skip_flag (device float, NULL: none): when *skip_flag != 0 the launch updates NOTHING -- the reference raises IndexError inside
+ * YOLOLoss.forward for a target that selects a box slot >= B (src/yolo/loss.py:112-118), i.e. before any parameter update; here the
+ * loss kernel's error word (out[5] of yolo_loss_fwd_bwd) is read by the host only after the step was enqueued, so the update
+ * kernels test it on the device. */
 #define YOLO_MT_MAX 48
 typedef struct yolo_adam_tensor {
     float *p;            /* parameter, updated in place */
@@ -431,14 +438,15 @@ typedef struct yolo_adam_tensor {
 } yolo_adam_tensor;
 int yolo_sumsq_f32_multi(const float *const *g, const long *n, int count, double *acc, yolo_stream_t stream);
 int yolo_adam_step_multi(const yolo_adam_tensor *t, int count, float lr, float beta1, float beta2, float eps,
-                         float weight_decay, long step, const double *norm_sq, float max_norm, yolo_stream_t stream);
+                         float weight_decay, long step, const double *norm_sq, float max_norm, const float *skip_flag,
+                         yolo_stream_t stream);
 /* The same update as a BACKGROUND pass: `workgroups` (1 .. 256) persistent workgroups of 1024 threads, each holding one CU to itself
  * (they reserve LDS they do not use), walk the elements.  An HBM-bound pass that occupies exactly that many CUs: launched on a
  * second stream it runs beside MFMA-bound kernels on the other CUs -- e.g. the update of the Linear layers (76 % of this model's
  * optimizer bytes, first used at the END of the next forward) beside the next forward's conv stack.  At most YOLO_MT_MAX tensors. */
 int yolo_adam_step_multi_bg(const yolo_adam_tensor *t, int count, float lr, float beta1, float beta2, float eps,
-                            float weight_decay, long step, const double *norm_sq, float max_norm, int workgroups,
-                            yolo_stream_t stream);
+                            float weight_decay, long step, const double *norm_sq, float max_norm, const float *skip_flag,
+                            int workgroups, yolo_stream_t stream);
 /* g *= min(1, max_norm / (sqrt(*norm_sq) + 1e-6))  (stand-alone clip_grad_norm_ for other optimizers). */
 int yolo_clip_scale_f32(float *g, long n, const double *norm_sq, float max_norm, yolo_stream_t stream);
 

@@ -36,8 +36,16 @@ def main():
         from yolo import engine
         open(out, "w").write(hashlib.sha256(y.cpu().numpy().tobytes()).hexdigest() + f" {len(engine._TUNED)}\n")
         return
-    use_dist = mode == "rccl"
-    if use_dist:
+    use_dist = mode in ("rccl", "gloo2")
+    rank, world = 0, 1
+    if mode == "gloo2":
+        # two ranks on ONE GPU (a dev box has one; RCCL refuses to use a device twice, gloo stages through the host): the shipped
+        # data-parallel path at a world size where averaging is not the identity
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(0)
+        dist.init_process_group("gloo")
+        rank, world = dist.get_rank(), dist.get_world_size()
+    elif use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
         dist.init_process_group("nccl", device_id=torch.device("cuda", torch.cuda.current_device()))
@@ -52,6 +60,10 @@ def main():
     red = make_grad_reducer(m, "cuda") if use_dist else None
     x = torch.from_numpy(synth.synth_images(4, 23)).cuda()
     t = torch.from_numpy(synth.synth_targets(4, 41, max_obj=3)).cuda()
+    if world > 1:
+        from yolo.parallel import shard_batch
+        sl = shard_batch(4, rank, world)
+        x, t = x[sl].contiguous(), t[sl].contiguous()
     opt.zero_grad(set_to_none=True)
     loss, parts = YOLOLoss()(m(x), t)
     loss.backward()
@@ -63,7 +75,7 @@ def main():
     torch.cuda.synchronize()
     params = {n: p.detach().float().cpu().clone() for n, p in m.named_parameters() if p.dim() == 1}
     torch.save({"loss": float(parts["total"]), "grads": grads, "norms": norms, "params": params,
-                "reducer": type(red).__name__ if red is not None else None}, out)
+                "reducer": type(red).__name__ if red is not None else None}, out if world == 1 else f"{out}.r{rank}")
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()

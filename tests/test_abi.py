@@ -40,7 +40,7 @@ def test_python_binding_covers_the_header():
 
 def test_abi_version_and_argument_errors(built):
     built.yolo_hip_abi_version.restype = ctypes.c_int
-    assert built.yolo_hip_abi_version() == 1
+    assert built.yolo_hip_abi_version() == 2
     # argument validation happens before any HIP call -> safe without a GPU
     built.yolo_decode.restype = ctypes.c_int
     rc = built.yolo_decode(None, 1, 7, 2, 20, ctypes.c_double(0.5), None, None, None)
@@ -69,4 +69,13 @@ def test_gpu_tensor_without_library_fails_loudly(monkeypatch):
     monkeypatch.setattr(_hip, "_LIB", None)
     monkeypatch.setattr(_hip, "LIB_PATH", "/nonexistent/libyolo_hip.so")
     with pytest.raises(RuntimeError, match="no CPU/eager fallback"):
+        _hip.lib()
+
+
+def test_binding_refuses_a_library_of_another_abi_version(monkeypatch, built):
+    """descriptors are passed by pointer: a library built from another header must not be bound"""
+    from yolo import _hip
+    monkeypatch.setattr(_hip, "_LIB", None)
+    monkeypatch.setattr(_hip, "ABI_VERSION", 99)
+    with pytest.raises(RuntimeError, match="ABI version"):
         _hip.lib()

@@ -52,3 +52,31 @@ def test_rccl_world1_overlapped_path_equals_single_process_step(tmp_path):
         assert abs(b["norms"][n] - v) <= 1e-4 * v + 1e-12, n
     for n, p in a["params"].items():
         torch.testing.assert_close(b["params"][n], p, rtol=1e-5, atol=1e-7, msg=n)
+
+
+def test_two_ranks_on_one_gpu_equal_the_single_process_step_on_the_whole_batch(tmp_path):
+    """at world size 1 a mean over ranks is the identity.  Two ranks (gloo; both on this box's one GPU) each take half of
+    the batch through the shipped path -- gradient arena, bucketed all-reduce overlapped with the two-stream backward pass, fused
+    clip + Adam: the ranks end bit-identical, and equal to the single-process step on all four images up to what a different batch
+    size changes (other launch plans -> other fp32 summation orders -> a few bf16 roundings)."""
+    plain, two = tmp_path / "plain.pt", tmp_path / "two.pt"
+    _run([CHILD, "plain", str(plain)])
+    port = 29900 + os.getpid() % 300
+    _run(["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+          CHILD, "gloo2", str(two)], timeout=900)
+    a = torch.load(plain, weights_only=True)
+    r0 = torch.load(str(two) + ".r0", weights_only=True)
+    r1 = torch.load(str(two) + ".r1", weights_only=True)
+    assert r0["reducer"] == r1["reducer"] == "OverlappedGradAllReduce"
+    for n in r0["params"]:
+        assert torch.equal(r0["params"][n], r1["params"][n]), n            # replicas stay identical (same averaged gradient, same clip norm)
+    for n in r0["grads"]:
+        assert torch.equal(r0["grads"][n], r1["grads"][n]), n
+    # mean of the two shard losses = loss of the whole batch (YOLOLoss divides by the local N, shards are equal)
+    assert abs(0.5 * (r0["loss"] + r1["loss"]) - a["loss"]) <= 2e-3 * abs(a["loss"])
+    for n, v in a["norms"].items():
+        assert abs(r0["norms"][n] - v) <= 2e-2 * v + 1e-9, (n, r0["norms"][n], v)
+    for n, g in a["grads"].items():
+        gg = r0["grads"][n].double().flatten()
+        cos = float((gg * g.double().flatten()).sum() / (gg.norm() * g.double().norm() + 1e-30))
+        assert cos > 0.995, (n, cos)

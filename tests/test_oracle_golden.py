@@ -146,3 +146,24 @@ def test_naive_layers_match_torch_fixtures(golden):
         np.testing.assert_allclose(y, g[f"{name}__y"], rtol=1e-4, atol=1e-5, err_msg=name)
     np.testing.assert_array_equal(O.maxpool2(g["pool__x"]), g["pool__y"])
     np.testing.assert_allclose(O.linear(g["fc__x"], g["fc__w"], g["fc__b"], slope=0.1), g["fc__y"], rtol=1e-4, atol=1e-5)
+
+
+def test_pure_python_postprocessing_matches_reference_fixtures(golden):
+    """oracle/post_py.py (the reference's per-scalar Python path, bench.py's second CPU leg) against the reference-run fixtures and
+    the crafted tie lists: bit-exact records and kept indices, like the C oracle"""
+    import torch
+    from oracle import post_py as PY
+    g = golden("post_cases.npz")
+    n_boxes = 0
+    for name in [str(n) for n in g["names"]][:6]:
+        pred = g[f"{name}__pred"]
+        ct, nt = g[f"{name}__thr"]
+        for n in range(min(pred.shape[0], 4)):
+            rec = PY.decode_py(torch.from_numpy(pred[n]), float(ct))
+            assert np.array_equal(rec, g[f"{name}__m{n}_dec"]), (name, n)
+            assert np.array_equal(PY.nms_py(rec, float(nt)), g[f"{name}__m{n}_keep"]), (name, n)
+            n_boxes += len(rec)
+    assert n_boxes > 300
+    for name in [str(n) for n in g["crafted"]] + ["negw"]:
+        rec = g[f"craft_{name}__in"]
+        assert np.array_equal(PY.nms_py(rec, float(g[f"craft_{name}__thr"][0])), g[f"craft_{name}__mkeep"]), name

@@ -363,3 +363,30 @@ def test_loss_parts_behaves_like_the_reference_dict():
         mk(1.0)["total"]
     with pytest.raises(RuntimeError, match="index out of bounds"):
         dict(mk(1.0))
+
+
+def test_bench_launches_its_own_ranks(monkeypatch, capsys):
+    """`python bench.py --gpus N` (no RANK in the environment) must itself start N ranks under torch.distributed.run
+    before touching a GPU, relay rank 0's JSON line, and fail when fewer than N devices are visible."""
+    import subprocess
+    import bench
+    monkeypatch.setattr(bench.torch.cuda, "device_count", lambda: 1)
+    with pytest.raises(SystemExit) as e:
+        bench._launch_ranks(8)
+    assert e.value.code == 2
+    seen = {}
+
+    def fake_run(cmd, stdout=None, env=None):
+        seen["cmd"], seen["env"] = cmd, env
+        return subprocess.CompletedProcess(cmd, 0, stdout=b"RCCL version 2.x banner\n{\"n_gpus\": 8}\n")
+    monkeypatch.setattr(bench.torch.cuda, "device_count", lambda: 8)
+    monkeypatch.setattr(subprocess, "run", fake_run)
+    monkeypatch.setattr(bench.sys, "argv", ["bench.py", "--gpus", "8", "--steps", "3"])
+    with pytest.raises(SystemExit) as e:
+        bench._launch_ranks(8)
+    assert e.value.code == 0
+    out = capsys.readouterr()
+    assert out.out.strip() == '{"n_gpus": 8}' and "banner" in out.err
+    cmd = seen["cmd"]
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node=8" in cmd and cmd[-4:] == ["--gpus", "8", "--steps", "3"]
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"

@@ -132,8 +132,9 @@ __global__ void __launch_bounds__(256) sumsq_multi_kernel(const SumsqTable tab, 
 }
 
 __global__ void __launch_bounds__(256) adam_multi_kernel(const AdamTable tab, float b1, float b2, float eps, float wd, float step_size, float inv_bc2_sqrt,
-                                                         const double *__restrict__ norm_sq, float max_norm)
+                                                         const double *__restrict__ norm_sq, float max_norm, const float *__restrict__ skip_flag)
 {
+    if (skip_flag && *skip_flag != 0.0f) return;      // the producer of the gradients flagged this step as invalid: nothing is updated
     float clip = 1.0f;
     if (norm_sq) {
         const float total = (float)sqrt(*norm_sq);
@@ -184,8 +185,10 @@ __global__ void __launch_bounds__(256) adam_multi_kernel(const AdamTable tab, fl
 // workgroups would starve, or be starved by, the conv kernels, whose workgroups need a whole CU each).  Four float4 per array and
 // thread are in flight: ~190 KB per CU, what ~100 GB/s per CU needs at HBM latency.
 __global__ void __launch_bounds__(1024) adam_multi_bg_kernel(const AdamTable tab, int chunks, float b1, float b2, float eps, float wd, float step_size,
-                                                             float inv_bc2_sqrt, const double *__restrict__ norm_sq, float max_norm)
+                                                             float inv_bc2_sqrt, const double *__restrict__ norm_sq, float max_norm,
+                                                             const float *__restrict__ skip_flag)
 {
+    if (skip_flag && *skip_flag != 0.0f) return;
     float clip = 1.0f;
     if (norm_sq) {
         const float total = (float)sqrt(*norm_sq);
@@ -338,7 +341,7 @@ YOLO_API int yolo_sumsq_f32_multi(const float *const *g, const long *n, int coun
 }
 
 YOLO_API int yolo_adam_step_multi(const yolo_adam_tensor *t, int count, float lr, float beta1, float beta2, float eps, float weight_decay, long step,
-                                  const double *norm_sq, float max_norm, yolo_stream_t stream)
+                                  const double *norm_sq, float max_norm, const float *skip_flag, yolo_stream_t stream)
 {
     if (!t || count < 0 || step < 1) return fail(YOLO_E_ARG, "yolo_adam_step_multi: bad argument");
     const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
@@ -363,7 +366,7 @@ YOLO_API int yolo_adam_step_multi(const yolo_adam_tensor *t, int count, float lr
         tab.count = k;
         if (chunks > 0) {
             hipLaunchKernelGGL(adam_multi_kernel, dim3((unsigned)chunks), dim3(256), 0, STRM(stream), tab, beta1, beta2, eps, weight_decay, step_size,
-                               inv_bc2_sqrt, norm_sq, max_norm);
+                               inv_bc2_sqrt, norm_sq, max_norm, skip_flag);
             if (int rc = check_launch("yolo_adam_step_multi")) return rc;
         }
         base += k;
@@ -372,7 +375,7 @@ YOLO_API int yolo_adam_step_multi(const yolo_adam_tensor *t, int count, float lr
 }
 
 YOLO_API int yolo_adam_step_multi_bg(const yolo_adam_tensor *t, int count, float lr, float beta1, float beta2, float eps, float weight_decay, long step,
-                                     const double *norm_sq, float max_norm, int workgroups, yolo_stream_t stream)
+                                     const double *norm_sq, float max_norm, const float *skip_flag, int workgroups, yolo_stream_t stream)
 {
     if (!t || count < 0 || count > YOLO_MT_MAX || step < 1 || workgroups < 1 || workgroups > 256)
         return fail(YOLO_E_ARG, "yolo_adam_step_multi_bg: bad argument (at most %d tensors, 1 .. 256 workgroups)", YOLO_MT_MAX);
@@ -404,7 +407,7 @@ YOLO_API int yolo_adam_step_multi_bg(const yolo_adam_tensor *t, int count, float
     }
     const int G = (int)std::min<long>(workgroups, chunks);
     hipLaunchKernelGGL(adam_multi_bg_kernel, dim3((unsigned)G), dim3(1024), BG_LDS, STRM(stream), tab, (int)chunks, beta1, beta2, eps, weight_decay, step_size, inv_bc2_sqrt,
-                       norm_sq, max_norm);
+                       norm_sq, max_norm, skip_flag);
     return check_launch("yolo_adam_step_multi_bg");
 }
 

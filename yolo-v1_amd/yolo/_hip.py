@@ -17,6 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("YOLO_HIP_LIB") or os.path.join(_HERE, "libyolo_hip.so")
 _LIB = None
 
+ABI_VERSION = 2              # YOLO_HIP_ABI_VERSION this binding was written against
 BN_ACC_REPLICAS = 16         # YOLO_BN_ACC_REPLICAS (include/yolo_hip.h)
 c_int, c_long, c_float, c_double, c_void_p = ctypes.c_int, ctypes.c_long, ctypes.c_float, ctypes.c_double, ctypes.c_void_p
 
@@ -150,8 +151,8 @@ _SIGS = {
     "yolo_pack_conv_weights_multi": [ctypes.POINTER(ConvPackItem), c_int, c_void_p],
     "yolo_unpack_conv_wgrads_multi": [ctypes.POINTER(ConvUnpackItem), c_int, c_void_p],
     "yolo_sumsq_f32_multi": [c_void_p, c_void_p, c_int, c_void_p, c_void_p],
-    "yolo_adam_step_multi": [ctypes.POINTER(AdamTensor), c_int, c_float, c_float, c_float, c_float, c_float, c_long, c_void_p, c_float, c_void_p],
-    "yolo_adam_step_multi_bg": [ctypes.POINTER(AdamTensor), c_int, c_float, c_float, c_float, c_float, c_float, c_long, c_void_p, c_float, c_int, c_void_p],
+    "yolo_adam_step_multi": [ctypes.POINTER(AdamTensor), c_int, c_float, c_float, c_float, c_float, c_float, c_long, c_void_p, c_float, c_void_p, c_void_p],
+    "yolo_adam_step_multi_bg": [ctypes.POINTER(AdamTensor), c_int, c_float, c_float, c_float, c_float, c_float, c_long, c_void_p, c_float, c_void_p, c_int, c_void_p],
     "yolo_bias_lrelu_rows": [c_void_p, c_void_p, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p],
     "yolo_bias_lrelu_rows_slabs": [c_void_p, c_int, c_void_p, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p],
 }
@@ -170,6 +171,11 @@ def lib():
                 f"{LIB_PATH} not found: the gfx950 HIP library is not built (run `make -C yolo-v1_amd/csrc` or "
                 "`python -c 'import __graft_entry__ as g; g.build()'`).  This package has no CPU/eager fallback for GPU tensors.")
         L = ctypes.CDLL(LIB_PATH)
+        L.yolo_hip_abi_version.argtypes, L.yolo_hip_abi_version.restype = [], c_int
+        if L.yolo_hip_abi_version() != ABI_VERSION:
+            # descriptors travel by pointer: a library built from another header would read (or leave unread) struct tails
+            raise RuntimeError(f"{LIB_PATH} has ABI version {L.yolo_hip_abi_version()}, this package binds version {ABI_VERSION}: rebuild it "
+                               "(`make -C yolo-v1_amd/csrc`)")
         for name, args in _SIGS.items():
             fn = getattr(L, name)  # AttributeError if the library lacks a declared symbol
             fn.argtypes = args

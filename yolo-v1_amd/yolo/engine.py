@@ -45,7 +45,6 @@ STEM_KERNEL = True  # 7x7/s2 stem through yolo_conv_stem7_fwd (False: the generi
 STEM_POOL_BWD_FUSED = True  # backward of the pool + LeakyReLU behind the stem inside yolo_wgrad_stem7_pooled (False: separate pass)
 STRIDE2_CLASSES = True  # data gradient of a stride-2 3x3 conv as four parity-class convs over the non-zero gradient slots
 _SIDE_STREAMS: dict = {}
-_PARAMS_READY: dict = {}     # id(plan) -> event behind a background optimizer launch (yolo.optim.Adam.attach_plan(overlap=True))
 SIDE_LOW = True      # ... of the lowest scheduling priority: the dispatcher prefers the data-gradient chain (12.73 -> 12.55 ms per step)
 WGRAD_STREAM = True  # backward: weight gradients run on a second HIP stream beside the data-gradient chain (they are off its critical path)
 WGRAD_SLABS = False  # pipelined weight-gradient kernel: partial tiles stored as slabs and summed in fixed order instead of fp32 atomics on the
@@ -67,18 +66,40 @@ def _igemm(L_, d, inp, w, bias, aux, out, st, what):
     check(L_.yolo_igemm(ctypes.byref(d), inp, w, bias, aux, out, st), what)
 
 
+class _Streams:
+    """where the executors get their streams from (tests of the stream schedule put recording stand-ins here)"""
+
+    @staticmethod
+    def current(dev):
+        return torch.cuda.current_stream(dev)
+
+    @staticmethod
+    def side(dev, low):
+        return _hip.side_stream(torch.device(dev), low=low)
+
+    @staticmethod
+    def use(s):
+        return torch.cuda.stream(s)
+
+
+STREAMS = _Streams()
+
+
 class _on_side_stream:
     """``with _on_side_stream(main, side) as st:`` -- work issued inside goes to ``side`` (None: stays on ``main``), behind everything
-    queued on ``main`` so far; ``st`` is the hipStream_t to launch on.  The caller joins with ``main.wait_stream(side)``."""
+    queued on ``main`` so far; ``st`` is the hipStream_t to launch on.  The caller joins with ``main.wait_stream(side)``.
+    ``note(waiter, waited)``: told about the wait (the gradient reducer keeps track of which stream has seen which)."""
 
-    def __init__(self, main_t, side_t):
-        self.main_t, self.side_t = main_t, side_t
+    def __init__(self, main_t, side_t, note=None):
+        self.main_t, self.side_t, self.note = main_t, side_t, note
 
     def __enter__(self):
         if self.side_t is None:
             return ctypes.c_void_p(self.main_t.cuda_stream)
         self.side_t.wait_stream(self.main_t)
-        self.ctx = torch.cuda.stream(self.side_t)
+        if self.note is not None:
+            self.note(self.side_t.cuda_stream, self.main_t.cuda_stream)
+        self.ctx = STREAMS.use(self.side_t)
         self.ctx.__enter__()
         return ctypes.c_void_p(self.side_t.cuda_stream)
 
@@ -432,6 +453,29 @@ def _tune_key(d: IgemmDesc):
 load_plans()
 
 
+class _EventSlot:
+    """holder of the event behind a background optimizer launch (yolo.optim.Adam.attach_plan(overlap=True)).  It lives on the plan
+    object (not in a table keyed by id(plan), which outlives garbage collection); a deep copy of a plan starts with an empty slot --
+    events do not copy, and the copy's parameters are new tensors nobody updates in the background."""
+
+    def __init__(self):
+        self.event = None
+
+    def __deepcopy__(self, memo):
+        return _EventSlot()
+
+    def __reduce__(self):
+        return (_EventSlot, ())
+
+    def wait(self, dev=None, keep: bool = False):
+        """the current stream waits for the pending update; ``keep``: leave the event in place for later readers on other streams"""
+        ev = self.event
+        if not keep:
+            self.event = None
+        if ev is not None:
+            torch.cuda.current_stream(dev).wait_event(ev)
+
+
 class Act:
     """Zero-haloed NHWC bf16 activation: [N][H+2h][W+2h][C] plus guard bands of zeros."""
 
@@ -514,8 +558,11 @@ class Plan:
         # gradients form a growing contiguous prefix that can be all-reduced while backward continues
         self.arena = None
         self.arena_views: dict[int, tuple] = {}
-        self.on_grad_ready = None    # callback(lo, hi): arena[lo:hi] (elements) is final
-        self.on_backward_done = None
+        self.on_grad_ready = None    # callback(lo, hi): arena[lo:hi] (elements) is final -- called with the PRODUCING stream current
+        self.on_backward_done = None # callback(): every gradient is final and the current stream has waited for all of them
+        self.on_stream_wait = None   # callback(waiter, waited): hipStream_t handles; `waiter` now waits for everything queued on `waited`
+        self.params_ready = _EventSlot()      # event behind a background update of the Linear layers (forward waits in front of them)
+        self.owner = None            # weakref to the nn.Module whose layers this plan runs (models.*.hip_plan sets it)
 
     def attach_grad_arena(self, device) -> torch.Tensor:
         """Allocate the gradient arena; backward then writes gradients into it, assigns ``p.grad`` views and
@@ -544,7 +591,7 @@ class Plan:
         objects, which are deep-copied with their modules)"""
         key = torch.device(dev).index
         if key not in _SIDE_STREAMS:
-            _SIDE_STREAMS[key] = _hip.side_stream(torch.device(dev), low=SIDE_LOW)
+            _SIDE_STREAMS[key] = STREAMS.side(dev, SIDE_LOW)
         return _SIDE_STREAMS[key]
 
     def _layer_done(self, li: int):
@@ -963,9 +1010,7 @@ class Plan:
                 check(L_.yolo_nhwc_bf16_to_nchw_bf16(cur.p, N, cur.C, cur.H, cur.W, cur.halo, ptr(nxt), st), "flatten")
                 cur = nxt
             elif L.kind == "fc":
-                ev = _PARAMS_READY.pop(id(self), None)
-                if ev is not None:       # yolo.optim.Adam(overlap): the Linear layers' update of the last step runs on a second stream
-                    torch.cuda.current_stream(dev).wait_event(ev)
+                self.params_ready.wait(dev)      # yolo.optim.Adam(overlap): the Linear layers' update of the last step runs on a second stream
                 if train:
                     wf, _ = self._pack(li, False)
                 else:
@@ -1126,11 +1171,11 @@ class Plan:
         # gradient and is first read by the optimizer.  The conv weight gradients (and their unpack passes / gradient-ready
         # callbacks) therefore go to a second stream: their atomic epilogues, partial last rounds and prologues -- phases in which a
         # kernel leaves the matrix cores idle -- overlap with the data-gradient kernels of the layers below, workgroup by workgroup.
-        main_t = torch.cuda.current_stream(dev)
+        main_t = STREAMS.current(dev)
         side_t = self._side_stream(dev) if (WGRAD_STREAM and TIMERS is None) else None
 
         def _on_side():
-            return _on_side_stream(main_t, side_t)
+            return _on_side_stream(main_t, side_t, self.on_stream_wait if self.arena is not None else None)
 
         # what each layer's input activation is
         def input_of(li):
@@ -1316,6 +1361,8 @@ class Plan:
                 if li == 0:
                     if side_t is not None:
                         main_t.wait_stream(side_t)       # every weight gradient is final before anything that follows the backward pass
+                        if self.arena is not None and self.on_stream_wait is not None:
+                            self.on_stream_wait(main_t.cuda_stream, side_t.cuda_stream)
                     gx = None
                     if need_gx:
                         if L.first:

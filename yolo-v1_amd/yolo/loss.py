@@ -46,11 +46,16 @@ class LossParts(dict):
     loss kernel; reading waits for that copy only.  A training loop that looks at the components after ``optimizer.step()`` (the
     reference's loop does, trainer.py:84-90) therefore never stalls the host in the middle of a step with nothing queued behind the
     loss: 12.32 -> 11.86 ms per step at batch 64 (tools/experiments/loss_sync_cost.py).  The reference's IndexError for a target
-    that selects a box slot >= B surfaces as RuntimeError at that first read (or at the next loss call, if the dict is never read)."""
+    that selects a box slot >= B surfaces as RuntimeError at that first read (or at the next loss call, if the dict is never read);
+    ``device_flag`` lets the optimizer skip the update of such a step on the device."""
 
-    def __init__(self, event, host):
+    def __init__(self, event, host, device_flag=None):
         super().__init__((k, None) for k in _KEYS)
         self._pending = (event, host)
+        # the kernel's error word on the device (one float32, non-zero = a target selected a box slot >= B): an optimizer that takes it
+        # (yolo.optim.Adam.skip_if; training.train_epoch passes it) updates nothing in a flagged step, so that the error raised at the
+        # first read finds the parameters as the reference's IndexError would have left them
+        self.device_flag = device_flag
 
     def _fetch(self):
         if self._pending is not None:
@@ -136,7 +141,7 @@ class YOLOLoss(nn.Module):
                 event = torch.cuda.Event()
                 event.record(cs)
             out.record_stream(cs)
-            parts = LossParts(event, host)
+            parts = LossParts(event, host, out[5:6])
             self._last_parts = parts
             return total, parts
         return self._forward_cpu(predictions, targets)

@@ -14,10 +14,32 @@ checkpoints written by the reference load unchanged.  What differs is ``forward`
 
 from __future__ import annotations
 
+import copy
+import weakref
+
 import torch
 import torch.nn as nn
 
 from . import engine
+
+
+class _PlanOwner:
+    """mix-in of the modules that own an engine plan: the plan knows its owner (hooks of yolo.optim.Adam.attach_plan(overlap=True)),
+    and a deep copy of the module first waits for a background update of its Linear layers still running on a second stream
+    (the copy reads every parameter on the current stream)."""
+
+    def _own(self, plan: "engine.Plan") -> "engine.Plan":
+        plan.owner = weakref.ref(self)
+        return plan
+
+    def __deepcopy__(self, memo):
+        plan = self.__dict__.get("_plan")
+        if isinstance(plan, engine.Plan):
+            plan.params_ready.wait(keep=True)
+        new = self.__class__.__new__(self.__class__)
+        memo[id(self)] = new
+        new.__setstate__(copy.deepcopy(self.__dict__, memo))       # what copy.deepcopy does for an nn.Module without this method
+        return new
 
 
 class Backbone(nn.Module):
@@ -34,7 +56,7 @@ def _conv_act(cin: int, cout: int, k: int, stride: int = 1, pad: int = 0) -> lis
     return [nn.Conv2d(cin, cout, kernel_size=k, stride=stride, padding=pad), nn.LeakyReLU(0.1)]
 
 
-class YOLOv1Backbone(Backbone):
+class YOLOv1Backbone(_PlanOwner, Backbone):
     """The 24-convolution network of the YOLOv1 paper: 448x448x3 -> 7x7x1024.
 
     Layer list = src/yolo/models.py:47-84 of the reference (indices inside ``features`` are part of
@@ -65,7 +87,7 @@ class YOLOv1Backbone(Backbone):
     def hip_plan(self) -> engine.Plan:
         if self._plan is None:
             self._plan = engine.Plan.from_modules(self.features, 3, True)
-        return self._plan
+        return self._own(self._plan)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         if x.is_cuda:
@@ -118,7 +140,7 @@ class ResNetBackbone(Backbone):
         return self.extractor(x)
 
 
-class DetectionHead(nn.Module):
+class DetectionHead(_PlanOwner, nn.Module):
     """Conv + FC head used on top of ResNet50 features (src/yolo/models.py:279-348):
     4 x (3x3 conv + LeakyReLU), the second with stride 2 (14x14 -> 7x7), then
     Flatten -> Linear(1024*S*S, 4096) -> LeakyReLU -> Dropout(0.5) -> Linear(4096, S*S*(5B+C))."""
@@ -138,7 +160,7 @@ class DetectionHead(nn.Module):
     def hip_plan(self) -> engine.Plan:
         if self._plan is None:
             self._plan = engine.Plan.from_modules(list(self.conv_layers) + list(self.fc_layers), self._in_channels, False)
-        return self._plan
+        return self._own(self._plan)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         if x.is_cuda:
@@ -148,7 +170,7 @@ class DetectionHead(nn.Module):
         return y.view(-1, self.S, self.S, self.B * 5 + self.num_classes)
 
 
-class YOLOv1(nn.Module):
+class YOLOv1(_PlanOwner, nn.Module):
     """Backbone + detection head -> (N, S, S, 5B + C) raw predictions (no output activation).
 
     ``YOLOv1()`` = YOLOv1Backbone + Flatten/Linear/LeakyReLU/Dropout/Linear head, exactly the
@@ -183,7 +205,7 @@ class YOLOv1(nn.Module):
     def hip_plan(self) -> engine.Plan:
         if self._plan is None:
             self._plan = engine.Plan.from_modules(list(self.backbone.features) + list(self.head), 3, True)
-        return self._plan
+        return self._own(self._plan)
 
     @torch.no_grad()
     def forward_uint8(self, images: torch.Tensor, size: tuple[int, int] = (448, 448)) -> torch.Tensor:

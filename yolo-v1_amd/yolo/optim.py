@@ -37,16 +37,15 @@ def grad_norm_sq(params, known=None) -> torch.Tensor:
     nn.Flatten while it stores it, yolo_wgrad_desc.dw_sumsq: 822 MB less to read).  An entry is used only while the parameter's
     .grad is still that very memory, unmodified (autograd hands over a detached alias that shares the version counter; accumulation,
     an all-reduce or clipping in place bump it)."""
-    grads, extra = [], []
-    for p in params:
-        if p.grad is None:
-            continue
-        k = known.get(id(p)) if known else None
-        if k is not None and k[0] == (p.grad.data_ptr(), tuple(p.grad.shape)) and k[1] == p.grad._version:
-            extra.append(k[2])
-        else:
-            grads.append(_f32c(p.grad))
+    grads, extra = _split_known(params, known)
     dev = (grads[0] if grads else extra[0]).device
+    if dev.type != "cuda":          # CPU parameters: stock torch ops (an explicit device choice, like the models' CPU path)
+        acc = torch.zeros((), dtype=torch.float64)
+        for g in grads:
+            acc += g.double().pow(2).sum()
+        for e in extra:
+            acc += e
+        return acc
     _hip.require_cuda(*grads)
     with torch.cuda.device(dev):
         acc = torch.zeros((), dtype=torch.float64, device=dev)
@@ -57,6 +56,21 @@ def grad_norm_sq(params, known=None) -> torch.Tensor:
         for e in extra:
             acc += e
     return acc
+
+
+def _split_known(params, known):
+    """(gradients whose squares must be summed, squared norms taken over from ``known``): an entry of ``known`` counts only while
+    the parameter's .grad is still the very memory it was computed from, at the same version"""
+    grads, extra = [], []
+    for p in params:
+        if p.grad is None:
+            continue
+        k = known.get(id(p)) if known else None
+        if k is not None and k[0] == (p.grad.data_ptr(), tuple(p.grad.shape)) and k[1] == p.grad._version:
+            extra.append(k[2])
+        else:
+            grads.append(_f32c(p.grad))
+    return grads, extra
 
 
 def clip_grad_norm_(parameters, max_norm: float) -> torch.Tensor:
@@ -89,6 +103,11 @@ class Adam(torch.optim.Optimizer):
         self.deferred: dict[int, object] = {}
         self._side = None
         self._pending = None                      # event behind the last background launch
+        # device float (or None), consumed by the next step(): non-zero = the producer of the gradients found its input invalid and
+        # the step must update nothing.  The training loop hands over YOLOLoss's error word (LossParts.device_flag), which the host
+        # reads only after the step was enqueued -- the reference raises inside the loss forward, before any update
+        self.skip_if = None
+        self._hooked: set = set()                 # ids of the modules that carry this optimizer's state_dict / load_state_dict hooks
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -99,9 +118,45 @@ class Adam(torch.optim.Optimizer):
         all_params = [p for g in self.param_groups for p in g["params"] if p.grad is not None]
         if not all_params:
             return loss
+        if all(not p.is_cuda for p in all_params):
+            self._step_on_cpu(all_params)
+            return loss
         _hip.require_cuda(*all_params)
         with torch.cuda.device(all_params[0].device):
             return self._step_on_device(all_params, loss)
+
+    def _step_on_cpu(self, all_params):
+        """CPU parameters (the reference's ``--device cpu`` runs, the gloo tests of the data-parallel path): the same step in stock
+        torch ops -- clip coefficient min(1, max_norm / (|g| + 1e-6)) from the squared norms (incl. the plans' hints), then the
+        arithmetic of adam1 in optim.hip, which is torch.optim.Adam's."""
+        known = {}
+        for plan in self.plans:
+            known.update(plan.grad_norm_sq)
+            plan.grad_norm_sq.clear()
+        clip = 1.0
+        if self.max_grad_norm is not None:
+            total = float(grad_norm_sq(all_params, known).sqrt())
+            clip = min(1.0, self.max_grad_norm / (total + 1e-6))
+        skip, self.skip_if = self.skip_if, None
+        if skip is not None and float(skip) != 0.0:
+            return
+        for group in self.param_groups:
+            b1, b2 = group["betas"]
+            for p in group["params"]:
+                if p.grad is None:
+                    continue
+                state = self.state[p]
+                if len(state) == 0:
+                    state["step"] = torch.tensor(0.0, dtype=torch.float32)
+                    state["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                    state["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                state["step"] += 1
+                t = int(state["step"].item())
+                g = p.grad.float() * clip + group["weight_decay"] * p
+                state["exp_avg"].lerp_(g, 1.0 - b1)
+                state["exp_avg_sq"].mul_(b2).addcmul_(g, g, value=1.0 - b2)
+                denom = state["exp_avg_sq"].sqrt() / ((1.0 - b2 ** t) ** 0.5) + group["eps"]
+                p.addcdiv_(state["exp_avg"], denom, value=-group["lr"] / (1.0 - b1 ** t))
 
     def _step_on_device(self, all_params, loss):
         known = {}
@@ -109,6 +164,11 @@ class Adam(torch.optim.Optimizer):
             known.update(plan.grad_norm_sq)
             plan.grad_norm_sq.clear()          # one backward pass, one use
         norm = grad_norm_sq(all_params, known) if self.max_grad_norm is not None else None
+        skip, self.skip_if = self.skip_if, None
+        if skip is not None:
+            if not (skip.is_cuda and skip.dtype == torch.float32 and skip.numel() == 1):
+                raise ValueError("skip_if must be one float32 on the device")
+            _hip.require_cuda(all_params[0], skip)
         st = stream()
         main_t = torch.cuda.current_stream()
         side_used = False
@@ -146,13 +206,15 @@ class Adam(torch.optim.Optimizer):
                         side.wait_stream(main_t)             # behind the gradients, the norm and the last forward's / backward's reads
                         if norm is not None:
                             norm.record_stream(side)
+                        if skip is not None:
+                            skip.record_stream(side)
                         side_used = True
                     check(lib().yolo_adam_step_multi_bg(tab, len(items), float(group["lr"]), float(b1), float(b2), float(group["eps"]),
-                                                        float(group["weight_decay"]), step, ptr(norm), float(self.max_grad_norm or 0.0), BG_CUS,
+                                                        float(group["weight_decay"]), step, ptr(norm), float(self.max_grad_norm or 0.0), ptr(skip), BG_CUS,
                                                         ctypes.c_void_p(side.cuda_stream)), "yolo_adam_step_multi_bg")
                 else:
                     check(lib().yolo_adam_step_multi(tab, len(items), float(group["lr"]), float(b1), float(b2), float(group["eps"]),
-                                                     float(group["weight_decay"]), step, ptr(norm), float(self.max_grad_norm or 0.0), st), "yolo_adam_step_multi")
+                                                     float(group["weight_decay"]), step, ptr(norm), float(self.max_grad_norm or 0.0), ptr(skip), st), "yolo_adam_step_multi")
                 for p, _, hook in items:
                     # the kernel updated p through a raw pointer: bump the autograd version so that the
                     # engine's packed bf16 copies notice (no memory traffic) ...
@@ -163,9 +225,8 @@ class Adam(torch.optim.Optimizer):
             ev = torch.cuda.Event()
             ev.record(self._side)
             self._pending = ev
-            from . import engine
-            for plan in self.deferred.values():
-                engine._PARAMS_READY[id(plan)] = ev     # Plan.forward waits for it in front of its first Linear layer
+            for plan in {id(pl): pl for pl in self.deferred.values()}.values():
+                plan.params_ready.event = ev            # Plan.forward waits for it in front of its first Linear layer
         return loss
 
     def _side_stream(self):
@@ -176,14 +237,39 @@ class Adam(torch.optim.Optimizer):
     def synchronize(self) -> None:
         """Make the CURRENT stream wait for a background update still running on the second stream (attach_plan(overlap=True)).
         The attached plan's forward does this by itself in front of its Linear layers; call it before reading those layers'
-        parameters or the optimizer state in any other way (state_dict() and zero_grad(set_to_none=False) do)."""
+        parameters or the optimizer state in any other way.  Waiting by themselves: this optimizer's state_dict() / load_state_dict() /
+        zero_grad(set_to_none=False), and the owning model's state_dict() / load_state_dict() / copy.deepcopy (hooks set by attach_plan)."""
         if self._pending is not None:
             torch.cuda.current_stream().wait_event(self._pending)
             self._pending = None
+            for plan in self.deferred.values():
+                plan.params_ready.event = None
+
+    def _hook_owner(self, plan) -> None:
+        """the module that owns ``plan`` waits for a background update by itself wherever torch reads or writes its parameters in
+        bulk: ``state_dict()`` (checkpoints, ``torch.save(model.state_dict())``), ``load_state_dict()`` (resume) and
+        ``copy.deepcopy`` (EMA copies; models.YOLOv1.__deepcopy__ asks the plan) -- no caller has to know about the second stream."""
+        owner = plan.owner() if getattr(plan, "owner", None) is not None else None
+        if owner is None or id(owner) in self._hooked:
+            return
+        self._hooked.add(id(owner))
+        import weakref
+        me = weakref.ref(self)
+
+        def wait(*_a, **_k):
+            opt = me()
+            if opt is not None:
+                opt.synchronize()
+        owner.register_state_dict_pre_hook(wait)
+        owner.register_load_state_dict_pre_hook(wait)
 
     def state_dict(self):
         self.synchronize()
         return super().state_dict()
+
+    def load_state_dict(self, state_dict):
+        self.synchronize()
+        return super().load_state_dict(state_dict)
 
     def zero_grad(self, set_to_none: bool = True):
         if not set_to_none:
@@ -203,5 +289,6 @@ class Adam(torch.optim.Optimizer):
         if overlap:
             for b in plan.fc_biases():
                 self.deferred[id(b)] = plan
+            self._hook_owner(plan)
         if all(pl is not plan for pl in self.plans):
             self.plans.append(plan)

@@ -74,32 +74,61 @@ class OverlappedGradAllReduce:
     optimizer) reduces the tail + the bias region and waits.  xGMI is point-to-point, so buckets are
     large (default 64 MB) and few."""
 
-    def __init__(self, plan, device, bucket_bytes: int = 64 << 20, group=None):
+    def __init__(self, plan, device, bucket_bytes: int = 64 << 20, group=None, stream_id=None):
         self.plan = plan
         self.group = group
         self.bucket = max(1, bucket_bytes // 4)
         self.arena = plan.arena if plan.arena is not None else plan.attach_grad_arena(device)
         plan.on_grad_ready = self._ready
         plan.on_backward_done = self._backward_done
+        plan.on_stream_wait = self._stream_wait
         self._sent = 0
         self._final = 0
         self._handles = []
         self._avg = dist.get_backend(group) == "nccl"     # RCCL has ReduceOp.AVG; gloo does not
+        # Stream bookkeeping.  A collective is ordered behind the work of the stream that is CURRENT when it is enqueued, and the plan's
+        # backward produces gradients on two streams (weight gradients of the conv layers on a low-priority side stream).  Every
+        # announced range remembers its producing stream and a tick; every stream wait the plan performs is noted with its tick; a
+        # bucket may only be enqueued from a stream that produced each of its pieces or has waited for the producer since.
+        self._stream_id = stream_id or (lambda: torch.cuda.current_stream(self.arena.device).cuda_stream if self.arena.is_cuda else 0)
+        self._tick = 0
+        self._pieces: list[tuple] = []        # (lo, hi, producing stream, tick) of the ranges announced in this backward pass
+        self._waits: dict[tuple, int] = {}    # (waiter, waited) -> tick of the last wait
+        self.log: list | None = None          # tests: (lo, hi, stream at the call, pieces) per enqueued bucket
+
+    def _stream_wait(self, waiter, waited):
+        self._tick += 1
+        self._waits[(waiter, waited)] = self._tick
+
+    def _check_ordered(self, lo: int, hi: int, cur):
+        for (a, b, s, t) in self._pieces:
+            if a < hi and b > lo and s != cur and self._waits.get((cur, s), -1) < t:
+                raise RuntimeError(f"gradient bucket [{lo}, {hi}) is being all-reduced from stream {cur:#x}, but its range [{a}, {b}) was "
+                                   f"produced on stream {s:#x}, which that stream has not waited for since: the collective could read an "
+                                   "unfinished gradient")
 
     def _reduce(self, lo: int, hi: int):
         if hi > lo:
+            cur = self._stream_id()
+            self._check_ordered(lo, hi, cur)
+            if self.log is not None:
+                self.log.append((lo, hi, cur, [p for p in self._pieces if p[0] < hi and p[1] > lo]))
             op = dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM
             self._handles.append(dist.all_reduce(self.arena[lo:hi], op=op, group=self.group, async_op=True))
 
     def _ready(self, lo: int, hi: int):
-        # layers complete in arena order, so [0, hi) is final
+        # layers complete in arena order, so [0, hi) is final; the caller is on the stream that produced [lo, hi)
+        self._tick += 1
+        self._pieces.append((lo, hi, self._stream_id(), self._tick))
         self._final = max(self._final, hi)
         if self._final - self._sent >= self.bucket:
             self._reduce(self._sent, self._final)
             self._sent = self._final
 
     def _backward_done(self):
-        self._reduce(self._sent, self.arena.numel())      # remaining weights + the whole bias region
+        # remaining weights + the whole bias region (bias gradients are accumulated by every layer's kernel, on either stream: the
+        # plan calls this after its main stream has waited for the side stream, which _check_ordered verifies for the weight ranges)
+        self._reduce(self._sent, self.arena.numel())
         self._sent = self.arena.numel()
 
     def finish(self) -> None:
@@ -108,8 +137,16 @@ class OverlappedGradAllReduce:
         self._handles = []
         if not self._avg:
             self.arena.mul_(1.0 / dist.get_world_size(self.group))
+        # The plan's backward left |g|^2 of the big Linear gradient as computed by the kernel that stored it -- the LOCAL gradient's.
+        # A collective does not bump the tensor's version counter (RCCL AVG works in place, no mul_), so the optimizer's
+        # "same memory, same version" test would take the stale per-rank norm for the clip and the replicas would drift apart.
+        # Drop the hint and bump the version: clip_grad_norm_ re-reads the averaged gradient.
+        self.plan.grad_norm_sq.clear()
+        torch.autograd.graph.increment_version(self.arena)
         self._sent = 0
         self._final = 0
+        self._pieces.clear()
+        self._waits.clear()
 
     # same entry point as GradAllReduce, so training loops can use either
     all_reduce_mean = finish

@@ -52,6 +52,10 @@ def train_epoch(model, dataloader, criterion, optimizer, device, epoch: int, wri
             allreduce.all_reduce_mean()
         if not fused_clip:
             torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm=_CLIP)
+        if hasattr(optimizer, "skip_if"):
+            # yolo.optim.Adam: a step whose targets the loss kernel flagged as invalid updates nothing (the error itself surfaces at
+            # the read of `parts` below; the reference raises inside the loss, before any update)
+            optimizer.skip_if = getattr(parts, "device_flag", None)
         optimizer.step()
         for k in _PARTS:
             sums[k] += parts[k]
