@@ -639,3 +639,73 @@ def test_streaming_1x1_kernel(cin, cout, epi, stride):
     halo = outs[19].view().clone()
     halo[:, 1: 1 + H, 1: 1 + W, :] = 0
     assert not bool(halo.any()), "the halo must stay zero"
+
+
+def _persist_problem(N, cin, cout, k, H, W, epi, pool=0, stride=1):
+    """one yolo_igemm problem on random data: (descriptor, input, weight panel, bias, aux, output Act)"""
+    from yolo import engine
+    from yolo._hip import EPI_BIAS_LRELU, EPI_MUL_DLRELU, EPI_NONE, IgemmDesc
+    g = torch.Generator(device="cuda").manual_seed(1000 * cin + cout + k)
+    pad = (k - 1) // 2
+    a_in = engine.Act(N, H, W, cin, 1, "cuda")
+    a_in.interior().copy_(torch.randn(N, H, W, cin, device="cuda", generator=g))
+    Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    a_out = engine.Act(N, Ho // 2 if pool else Ho, Wo // 2 if pool else Wo, cout, 1, "cuda")
+    aux = engine.Act(N, Ho, Wo, cout, 1, "cuda")
+    aux.interior().copy_(torch.randn(N, Ho, Wo, cout, device="cuda", generator=g))
+    w = (torch.randn(cout, k, k, cin, device="cuda", generator=g) / (k * k * cin) ** 0.5).to(torch.bfloat16)
+    b = torch.randn(cout, device="cuda", generator=g)
+    d = IgemmDesc()
+    d.N, d.Ho, d.Wo = N, Ho, Wo
+    d.in_img_stride, d.in_row_stride, d.in_px_stride, d.in_off = a_in.img_stride, a_in.row_stride, a_in.px_stride, a_in.interior_off(pad)
+    d.stride, d.KH, d.KW, d.tap_len, d.Cout = stride, k, k, cin, cout
+    d.out_img_stride, d.out_row_stride, d.out_px_stride, d.out_off = a_out.img_stride, a_out.row_stride, a_out.px_stride, a_out.interior_off()
+    d.aux_img_stride, d.aux_row_stride, d.aux_px_stride, d.aux_off = aux.img_stride, aux.row_stride, aux.px_stride, aux.interior_off()
+    d.epilogue = {"lrelu": EPI_BIAS_LRELU, "gate": EPI_MUL_DLRELU, "none": EPI_NONE}[epi]
+    d.slope, d.out_fp32, d.split_k, d.pool2 = 0.1, 0, 1, pool
+    return d, a_in, w, b, aux, a_out
+
+
+@pytest.mark.parametrize("cin,cout,k,epi,tpx", [(64, 512, 3, "lrelu", 196), (64, 512, 3, "lrelu", 208), (192, 256, 1, "lrelu", 196), (256, 512, 1, "gate", 196),
+                                                 (128, 256, 3, "gate", 208), (64, 192, 3, "lrelu", 196), (512, 256, 1, "none", 100), (64, 256, 3, "lrelu", 224)])
+def test_persistent_kernel_equals_the_pipelined_one(cin, cout, k, epi, tpx):
+    """igemm_persist.hip (tile_hint 20 / 21): several tiles per workgroup in ONE software pipeline (61 440 pixels: 296-615 pixel tiles x
+    1-2 channel tiles for 256 workgroups), table of the next tile built under the K loop, epilogue straight out of the accumulator
+    registers -- the same MFMAs in the same order as tile_hint 15 / 16, so every output is bit-identical; also run twice (no
+    run-to-run differences: the duplicate stores of a tile's idle pixel slots write identical bits)."""
+    from yolo import engine
+    from yolo._hip import lib, ptr, stream
+    d, a_in, w, b, aux, a_out = _persist_problem(8, cin, cout, k, 80, 96, epi)
+    hint = 21 if tpx == 224 else 20
+
+    def run(pl):
+        a_out.t.fill_(7.0)
+        engine._run_plan_igemm(lib(), d, pl, a_in.p, ptr(w), ptr(b) if epi == "lrelu" else None, aux.p if epi == "gate" else None, a_out.p, stream(), "test")
+        return a_out.interior().clone()
+
+    ref = run(("tile", 16 if tpx == 224 else 15, 1, 0 if tpx == 224 else tpx))
+    got = run(("tile", hint, 1, 0 if tpx == 224 else tpx))
+    assert torch.isfinite(got.float()).all()
+    assert torch.equal(got, ref), (got.float() - ref.float()).abs().max().item()
+    assert torch.equal(run(("tile", hint, 2, 0 if tpx == 224 else tpx)), ref)          # the other tile order
+    assert torch.equal(a_out.view()[:, 0], torch.full_like(a_out.view()[:, 0], 7.0))   # the halo is never written
+
+
+@pytest.mark.parametrize("W,H,cin,cout", [(112, 16, 64, 192), (56, 56, 128, 256), (28, 28, 256, 512)])
+def test_persistent_kernel_fuses_the_pool(W, H, cin, cout):
+    """tile_hint 21 with pool2 = 1: the 2x2 windows sit on lane quads (address table), maximum by DPP quad permutes, one 8-byte store per
+    lane and column -- bit-identical to the pooled epilogue of tile_hint 16 (through LDS)."""
+    from yolo import engine
+    from yolo._hip import lib, ptr, stream
+    N = 16 if W == 28 else 8
+    d, a_in, w, b, aux, a_out = _persist_problem(N, cin, cout, 3, H, W, "lrelu", pool=1)
+
+    def run(pl):
+        a_out.t.fill_(7.0)
+        engine._run_plan_igemm(lib(), d, pl, a_in.p, ptr(w), ptr(b), None, a_out.p, stream(), "test")
+        return a_out.interior().clone()
+
+    ref = run(("tile", 16, 1, 0))
+    got = run(("tile", 21, 1, 0))
+    assert torch.equal(got, ref), (got.float() - ref.float()).abs().max().item()
+    assert torch.equal(a_out.view()[:, 0], torch.full_like(a_out.view()[:, 0], 7.0))

@@ -615,3 +615,56 @@ def test_adam_takes_the_big_linear_gradient_norm_from_the_weight_gradient_kernel
     assert abs(full - hinted) <= 1e-5 * full
     big.grad.mul_(2.0)                                   # modified in place: the stored norm no longer describes it
     assert abs(grad_norm_sq(params, plan.grad_norm_sq).item() - grad_norm_sq(params).item()) <= 1e-9 * full
+
+
+def test_flagged_step_updates_nothing_and_model_reads_wait_for_the_background_update():
+    """(1) the loss kernel's error word (a target selecting a box slot >= B; the reference raises IndexError inside the loss,
+    before any update) reaches the host only after optimizer.step() was enqueued: handed to the optimizer as ``skip_if`` the whole
+    update -- foreground and background launches -- is a no-op on the device, and the error surfaces at the first read of the parts;
+    (2) with attach_plan(overlap=True) the owning model's state_dict() / load_state_dict() / deepcopy wait for the background pass by
+    themselves."""
+    import copy
+    from yolo import YOLOLoss, YOLOv1
+    from yolo.optim import Adam
+    torch.manual_seed(5)
+    m = YOLOv1().cuda().train()
+    opt = Adam(m.parameters(), lr=1e-3, weight_decay=5e-4, max_grad_norm=10.0)
+    opt.attach_plan(m.hip_plan(), overlap=True)
+    assert opt._hooked, "the model that owns the plan carries the state_dict hooks"
+    x = torch.from_numpy(synth.synth_images(2, 3)).cuda()
+    tgt = torch.from_numpy(synth.synth_targets(2, 4)).cuda()
+    crit = YOLOLoss()
+
+    def one_step(t):
+        opt.zero_grad(set_to_none=True)
+        loss, parts = crit(m(x), t)
+        loss.backward()
+        opt.skip_if = parts.device_flag
+        opt.step()
+        return parts
+
+    parts = one_step(tgt)
+    sd1 = {k: v.detach().clone() for k, v in m.state_dict().items()}        # (2): waits for the background update of the Linear layers
+    before = {k: v.clone() for k, v in sd1.items()}
+    assert float(parts["total"]) > 0
+    assert any(not torch.equal(sd1[k], v) for k, v in copy.deepcopy(m).state_dict().items()) is False
+    bad = tgt.clone()
+    bad[0, 1, 1, 14] = 1.0                       # channel 14 is a class channel: 4::5 selects "slot 2" of a B = 2 model
+    bad[0, 1, 1, 4] = 0.0
+    bad[0, 1, 1, 9] = 0.0
+    parts = one_step(bad)
+    with pytest.raises(RuntimeError, match="box slot"):
+        parts["total"]
+    torch.cuda.synchronize()
+    after = m.state_dict()
+    for k, v in before.items():
+        assert torch.equal(after[k], v), f"{k} changed in a flagged step"
+    st = opt.state_dict()["state"]
+    assert all(float(s["exp_avg"].abs().max()) > 0 for s in st.values())      # the first (valid) step did update
+    parts = one_step(tgt)                        # and training goes on
+    assert float(parts["total"]) > 0
+    changed = sum(not torch.equal(m.state_dict()[k], v) for k, v in before.items())
+    assert changed == len(before)
+    m.load_state_dict(sd1)                       # (2): load waits as well
+    for k, v in m.state_dict().items():
+        assert torch.equal(v, sd1[k])

@@ -847,6 +847,7 @@ YOLO_API int yolo_igemm(const yolo_igemm_desc *d, const void *in, const void *w,
     if (p.pool && d->tile_px) return fail(YOLO_E_UNSUPPORTED, "yolo_igemm: tile_px is not available with pool2");
     if (p.pool && (splits > 1 || d->out_fp32 || (d->Ho & 1) || (d->Wo & 1) || (d->epilogue != YOLO_EPI_BIAS && d->epilogue != YOLO_EPI_BIAS_LRELU)))
         return fail(YOLO_E_UNSUPPORTED, "yolo_igemm: pool2 needs even Ho/Wo, bf16 output, a bias epilogue and no split-K");
+    if (force == 20 || force == 21) return igemm_persist_launch(p, force, splits, s);   // persistent loop, epilogue from the accumulator registers (igemm_persist.hip)
     if (p.pool == 3 && !(force >= 15 && force <= 18)) {
         // pooled map + arg-max codes: the two 8 x 16-patch configurations in their own instantiations (VAR 2), whatever the hint
         if (!bk64 || d->w_blocked || p.stats) return fail(YOLO_E_UNSUPPORTED, "yolo_igemm: pool2 = 3 needs tap_len %% 64 == 0 (or tile_hint 16 / 18), plain weights, no bn_stats");

@@ -48,6 +48,8 @@ struct IgemmParams {
     long *dbg;              // diagnostic builds (-DIGEMM_STAMPS) only: s_memtime stamps of K iteration dbg_it, see yolo_debug_stamps
     int dbg_it;
     double *stats;          // != nullptr: per-channel sum / sum of squares of the (bf16-rounded) outputs, see yolo_igemm_desc.bn_stats
+    // igemm_persist.hip: divisions of the address table as multiply-high (floor(n / d) = umulhi(n, magic) >> shift, n < 2^31; magic 0: d = 1)
+    unsigned div_hw_magic, div_hw_shift, div_w_magic, div_w_shift, div_hw2_magic, div_hw2_shift;   // d = HoWo, Wo, Wo / 2
 };
 
 #define GLDS16(gptr, lptr) \
@@ -86,6 +88,8 @@ __device__ __forceinline__ void wait_vmcnt()
 
 // igemm_pipe.hip: the register-pipelined one-barrier kernels (tile_hint 15 .. 18); `splits` as for the other configurations
 int igemm_pipe_launch(const IgemmParams &p, int hint, int splits, hipStream_t s);
+// igemm_persist.hip: persistent register-pipelined kernels with the epilogue out of the accumulator registers (tile_hint 20 / 21)
+int igemm_persist_launch(const IgemmParams &p, int hint, int splits, hipStream_t s);
 // igemm_stream.hip: streaming 1x1 convolution of the thin-K pointwise layers (tile_hint 19)
 int igemm_stream_launch(const IgemmParams &p, int splits, hipStream_t s);
 

@@ -1,0 +1,578 @@
+// Persistent register-pipelined implicit-GEMM kernels for gfx950 (tile_hint 20 / 21): the K loop of igemm_pipe.hip (256 channels x
+// 16 * NTILES pixel slots, BK = 32, four LDS stages, ONE barrier per K step, two register sets of fragments) run as ONE software
+// pipeline over ALL the tiles of a workgroup:
+//
+//   * one workgroup per CU walks tiles b, b + G, b + 2G, .. ; the LDS-DMA of the next tile's first three stages is issued under the
+//     last three K steps of the current tile, the fragments of its step 0 are read under the current tile's last MFMAs -- the first
+//     stage's HBM / L2 latency (4-6 k cycles per tile in igemm_pipe, in-kernel stamps) is paid once per workgroup, not once per tile;
+//   * the per-pixel address table of tile t + 1 is built under tile t's K loop (two table buffers; divisions by multiply-high);
+//   * the EPILOGUE RUNS FROM THE ACCUMULATOR REGISTERS: in the 16x16x32 result layout a lane holds 4 consecutive channels of one
+//     pixel, so bias / LeakyReLU / LeakyReLU' / bf16 packing happen in place and each accumulator tile leaves as one 8-byte store
+//     per lane (32 contiguous bytes per pixel and instruction, 128 B per pixel over a wave's four channel tiles; L2 merges them into
+//     whole lines).  No LDS slab, no second pass, no barrier: ~2-3 k cycles per tile against 13-15 k of the LDS epilogue, and the
+//     stores drain under the next tile's K loop (the counted vmcnt waits of its first two steps leave them in flight);
+//   * hint 21 (224-pixel tiles of whole row pairs) fuses MaxPool2d(2,2): the address table puts the four pixels of a pooling window
+//     on four NEIGHBOURING LANES of one accumulator column, so the window maximum is two DPP quad-permute max operations per value;
+//     lane e of a quad then stores channel tile e of the pooled pixel -- again one 8-byte store per lane, a quarter of the bytes.
+//
+// Pixel slots beyond a tile's valid pixels compute (and store) the true values of the pixels they would hold in the flat order --
+// identical bits written twice -- so that every wave issues the SAME number of stores in every epilogue: the vmcnt arithmetic of
+// the first two K steps behind an epilogue depends on it.
+// Reference arithmetic: nn.Conv2d + nn.LeakyReLU(0.1) (+ nn.MaxPool2d(2,2)), src/yolo/models.py:47-84.
+#include "igemm_common.h"
+
+namespace yolo {
+
+template <int NTILES_>
+struct PersistCfg {
+    static constexpr int TCO = 256, NTILES = NTILES_, NST = 4, BK = 32;
+    static constexpr int TPX = 16 * NTILES;
+    static constexpr int WCO = 4, NW = 8, NTHR = 512;
+    static constexpr int MT = 4, NT0 = 7, NT1 = NTILES - 7;
+    static constexpr int A_BYTES = TCO * BK * 2;
+    static constexpr int B_BYTES = 256 * BK * 2;
+    static constexpr int STAGE_BYTES = A_BYTES + B_BYTES;
+    static constexpr int A_PIECES = A_BYTES / 1024 / NW, B_PIECES = B_BYTES / 1024 / NW;
+    static constexpr int LOADS = A_PIECES + B_PIECES;
+    static constexpr int TABLE_BYTES = 256 * 16;            // one table: 16 B per pixel slot {in, out, aux byte offsets, -}
+    static constexpr int STASH_BYTES = NW * 64 * 4;         // per-wave bias stash
+    static constexpr int LDS_BYTES = 2 * TABLE_BYTES + STASH_BYTES + NST * STAGE_BYTES;
+    static constexpr int D = NST - 1;
+    static_assert(NT1 >= 1 && NT1 <= NT0, "pixel group B holds 1 .. 7 columns");
+};
+
+__device__ __forceinline__ unsigned fast_div(unsigned n, unsigned magic, unsigned shift)
+{
+    return magic ? (__umulhi(n, magic) >> shift) : n;       // magic 0: divisor 1
+}
+
+// The lane id, recomputed where it is used: everything the per-tile code derives from it (table slots, stash and output offsets) would
+// otherwise be hoisted out of the tile loop as loop invariants and -- at ~250 live registers in the K loop -- spilled to scratch, whose
+// reloads wait for vmcnt(0), i.e. for the previous tile's stores and the next tile's stages.  (volatile: not hoisted, not merged)
+__device__ __forceinline__ int fresh_lane()
+{
+    int l;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+    return l;
+}
+
+__device__ __forceinline__ float quad_max(float v)
+{
+    // maximum over the four lanes of a quad: quad_perm [1,0,3,2] then [2,3,0,1]
+    const float a = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+    const float m = fmaxf(v, a);
+    const float b = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, m), 0x4E, 0xF, 0xF, true));
+    return fmaxf(m, b);
+}
+
+// 8-byte store: scalar base + 32-bit byte offset per lane + immediate.  Inline asm: exactly one VMEM instruction per call, whatever
+// the optimiser thinks (the waits behind an epilogue count them).
+template <int IMM>
+__device__ __forceinline__ void store8(const void *base, unsigned voff, unsigned lo, unsigned hi)
+{
+    typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+    const u32x2 d = {lo, hi};
+    asm volatile("global_store_dwordx2 %0, %1, %2 offset:%3" ::"v"(voff), "v"(d), "s"(base), "n"(IMM) : "memory");
+}
+
+// DGRAD: the instantiation whose epilogue multiplies by LeakyReLU'(aux) (its 56 registers of aux vectors stay out of the others)
+template <int IMM>
+__device__ __forceinline__ void store16(const void *base, unsigned voff, unsigned a, unsigned b, unsigned c, unsigned d)
+{
+    typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+    const u32x4 v = {a, b, c, d};
+    asm volatile("global_store_dwordx4 %0, %1, %2 offset:%3" ::"v"(voff), "v"(v), "s"(base), "n"(IMM) : "memory");
+}
+
+// v_permlane16_swap_b32: rows (16 lanes) 1 and 3 of x change places with rows 0 and 2 of y
+__device__ __forceinline__ void row_swap(float &x, float &y)
+{
+    typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+    const u32x2 r = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, x), __builtin_bit_cast(unsigned, y), false, false);
+    x = __builtin_bit_cast(float, r.x);
+    y = __builtin_bit_cast(float, r.y);
+}
+
+template <int NTILES, bool POOL, bool DGRAD>
+__global__ void __launch_bounds__(512, 2) igemm_persist_kernel(const IgemmParams p)
+{
+    using C = PersistCfg<NTILES>;
+    constexpr int TPX = C::TPX, BK = C::BK, NW = C::NW, WCO = C::WCO, MT = C::MT, NT0 = C::NT0, NT1 = C::NT1, NST = C::NST;
+    constexpr int A_BYTES = C::A_BYTES, STAGE_BYTES = C::STAGE_BYTES, LOADS = C::LOADS, D = C::D, TCO = C::TCO;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    unsigned *tab = reinterpret_cast<unsigned *>(smem);                         // [2][256][4]
+    float *stash = reinterpret_cast<float *>(smem + 2 * C::TABLE_BYTES);        // [NW][64]
+    char *stage_base = smem + 2 * C::TABLE_BYTES + C::STASH_BYTES;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wco = wave % WCO, grp = wave / WCO;
+    const int px_lo = grp * NT0 * 16;
+
+#ifdef IGEMM_STAMPS
+    // diagnostic build: [0] kernel start | [1] stage 0 visible | [2] / [3] end of tile 0's K loop / epilogue | [4] / [5] the same of tile 1 |
+    // [6] end of the last tile's K loop | [7] kernel end -- per wave of the first 512 workgroups (tools/stamps_persist.py)
+    long tstamp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    tstamp[0] = __builtin_amdgcn_s_memtime();
+#define PSTAMP(i) do { __builtin_amdgcn_sched_barrier(0); tstamp[i] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define PSTAMP(i) do { } while (0)
+#endif
+    const int T = p.n_co_tiles * p.n_px_tiles;
+    const int G = gridDim.x;
+    const int n_mine = (T - (int)blockIdx.x + G - 1) / G;
+    const int tpv = p.tpx_valid;
+
+    // tile i of this workgroup -> (first channel, first pixel); XCD-aware bijective map of the virtual block id (igemm.hip)
+    auto tile_of = [&](int i, int &co0, unsigned &px0) {
+        const int v = (int)blockIdx.x + i * G;
+        const int q = T >> 3, r = T & 7, xcd = v & 7, k = v >> 3;
+        const int bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+        const int co_tile = p.px_fastest ? bid / p.n_px_tiles : bid % p.n_co_tiles;
+        const int px_tile = p.px_fastest ? bid % p.n_px_tiles : bid / p.n_co_tiles;
+        co0 = co_tile * TCO;
+        px0 = (unsigned)px_tile * (unsigned)tpv;
+    };
+
+    // address table of one tile: byte offsets of the pixel's input row base / output / aux element 0
+    auto build_table = [&](int buf, unsigned px0) {
+        const int tid = wave * 64 + fresh_lane();
+        if (tid < TPX) {
+            unsigned m;
+            if constexpr (POOL) {
+                // slot = 16 * column + 4 * window-in-column + element: the four pixels of a 2x2 window are four neighbouring lanes
+                const unsigned W = (unsigned)(tid >> 4) * 4 + (unsigned)((tid >> 2) & 3), e = (unsigned)tid & 3;
+                const unsigned hw = (unsigned)p.Wo >> 1;
+                const unsigned wy = fast_div(W, p.div_hw2_magic, p.div_hw2_shift), wx = W - wy * hw;
+                m = px0 + (2 * wy + (e >> 1)) * (unsigned)p.Wo + 2 * wx + (e & 1);
+            } else {
+                m = px0 + (unsigned)tid;
+            }
+            if (m >= (unsigned)p.M) m = (unsigned)p.M - 1;           // past the end: the last pixel once more (same bits)
+            const unsigned n = fast_div(m, p.div_hw_magic, p.div_hw_shift);
+            const unsigned rem = m - n * (unsigned)p.HoWo;
+            const unsigned oy = fast_div(rem, p.div_w_magic, p.div_w_shift), ox = rem - oy * (unsigned)p.Wo;
+            const long in_e = (long)n * p.in_img_stride + (long)(oy * p.stride) * p.in_row_stride + (long)(ox * p.stride) * p.in_px_stride + p.in_off;
+            const unsigned qy = POOL ? oy >> 1 : oy, qx = POOL ? ox >> 1 : ox;
+            const long out_e = (long)n * p.out_img_stride + (long)qy * p.out_row_stride + (long)qx * p.out_px_stride + p.out_off;
+            const long aux_e = (long)n * p.aux_img_stride + (long)oy * p.aux_row_stride + (long)ox * p.aux_px_stride + p.aux_off;
+            uint4 ent;
+            ent.x = (unsigned)(in_e * 2);
+            ent.y = (unsigned)(out_e * 2);
+            ent.z = (unsigned)(aux_e * 2);
+            ent.w = 0;
+            *reinterpret_cast<uint4 *>(tab + (buf * 256 + tid) * 4) = ent;
+        }
+    };
+
+    // LDS-DMA source lanes (inverse swizzle, igemm.hip): weight rows relative to the tile's first channel, pixel rows from the table
+    unsigned a_voff[C::A_PIECES], b_voff[C::B_PIECES];
+#pragma unroll
+    for (int i = 0; i < C::A_PIECES; ++i) {
+        const int pos = (i * NW + wave) * 64 + lane;
+        const int R = pos >> 4, s = (pos & 15) ^ swz_key<BK, true>(R);
+        int r = R * 4 + s / 4;
+        const int chunk = s % 4;
+        if (r >= p.Cout) r = p.Cout - 1;                     // (a single ragged channel tile; several tiles: Cout % 256 == 0, host-checked)
+        a_voff[i] = (unsigned)(((long)r * p.Ktot + chunk * 8) * 2);
+    }
+    // (recomputed per tile rather than kept: the K loop runs at ~250 live registers)
+    auto load_b_voff = [&](int buf) {
+        const int lane = fresh_lane();
+#pragma unroll
+        for (int i = 0; i < C::B_PIECES; ++i) {
+            const int pos = (i * NW + wave) * 64 + lane;
+            const int R = pos >> 4, s = (pos & 15) ^ swz_key<BK, true>(R);
+            const int r = R * 4 + s / 4;
+            b_voff[i] = tab[(buf * 256 + (r < TPX ? r : 0)) * 4] + (unsigned)((s % 4) * 16);
+        }
+    };
+
+    const int nk = p.nk;
+    const int cpt = p.tap_len / BK;
+    // scalar staging state of the tile being STAGED (the current tile, or the next one in a tile's last three steps)
+    unsigned a_soff = 0;          // byte offset of the step's weight columns + of the tile's first weight row
+    int c0 = 0, ky = 0, kx = 0;
+    (void)cpt;
+
+    auto stage = [&](int buf) {
+        char *sb = stage_base + buf * STAGE_BYTES + wave * 1024;
+        const unsigned b_soff = (unsigned)((ky * p.in_row_stride + kx * p.in_px_stride + c0) * 2);
+        const char *wb = reinterpret_cast<const char *>(p.w) + a_soff;
+        const char *xb = reinterpret_cast<const char *>(p.in) + b_soff;
+#pragma unroll
+        for (int i = 0; i < C::A_PIECES; ++i)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(wb + (unsigned long)a_voff[i]),
+                                             (__attribute__((address_space(3))) void *)(sb + i * NW * 1024), 16, 0, 0);
+#pragma unroll
+        for (int i = 0; i < C::B_PIECES; ++i)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(xb + (unsigned long)b_voff[i]),
+                                             (__attribute__((address_space(3))) void *)(sb + A_BYTES + i * NW * 1024), 16, 0, 0);
+        a_soff += BK * 2;
+        c0 += BK;
+        const int w0 = c0 == p.tap_len;
+        c0 = w0 ? 0 : c0;
+        kx += w0;
+        const int w1 = kx == p.KW;
+        kx = w1 ? 0 : kx;
+        ky += w1;
+    };
+    auto stage_reset = [&](int co0) {
+        a_soff = (unsigned)((long)co0 * p.Ktot * 2);
+        c0 = 0; ky = 0; kx = 0;
+    };
+
+    // fragment read offsets: 16 rows further = 4 bank rows (1 KB) further with the same swizzle key -> one base register per operand,
+    // the tiles as immediate offsets
+    const int a_rd0 = lds_off<BK, true>(wco * 64 + (lane & 15), lane >> 4);
+    const int b_rd0 = A_BYTES + lds_off<BK, true>(px_lo + (lane & 15), lane >> 4);
+
+    f32x4 acc[MT][NT0];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT0; ++j) acc[i][j] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+
+    // ---- prologue: table + bias stash of tile 0, its first D stages in flight, stage 0 landed and visible
+    int co0_cur;
+    unsigned px0_cur;
+    tile_of(0, co0_cur, px0_cur);
+    build_table(0, px0_cur);
+    const bool has_bias = p.epilogue == YOLO_EPI_BIAS || p.epilogue == YOLO_EPI_BIAS_LRELU;
+    auto load_stash = [&](int co0) {
+        const int lane = fresh_lane();
+        const int ch = co0 + wco * 64 + lane;
+        stash[wave * 64 + lane] = (has_bias && ch < p.Cout) ? p.bias[ch] : 0.0f;
+    };
+    load_stash(co0_cur);
+    __syncthreads();
+    load_b_voff(0);
+    stage_reset(co0_cur);
+#pragma unroll
+    for (int s0 = 0; s0 < D; ++s0) stage(s0);
+    wait_vmcnt<(D - 1) * LOADS>();
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    PSTAMP(1);
+
+    auto run = [&](auto ntc) {
+        constexpr int NTG = decltype(ntc)::value;
+        bf16x8 a0[MT], b0[NT0], a1[MT], b1[NT0];
+        auto rd = [&](int buf, bf16x8(&af)[MT], bf16x8(&bfr)[NT0]) {
+            const char *sb = stage_base + buf * STAGE_BYTES;
+#pragma unroll
+            for (int i = 0; i < MT; ++i) af[i] = *reinterpret_cast<const bf16x8 *>(sb + a_rd0 + i * 1024);
+#pragma unroll
+            for (int j = 0; j < NTG; ++j) bfr[j] = *reinterpret_cast<const bf16x8 *>(sb + b_rd0 + j * 1024);
+        };
+        auto mm = [&](bf16x8(&af)[MT], bf16x8(&bfr)[NT0]) {
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NTG; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+        };
+        constexpr int NRD = MT + NTG, NMF = MT * NTG;
+        auto body = [&](int rbuf, int lbuf, bf16x8(&ca)[MT], bf16x8(&cb)[NT0], bf16x8(&na)[MT], bf16x8(&nb)[NT0]) {
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            rd(rbuf, na, nb);
+            stage(lbuf);
+            mm(ca, cb);
+#pragma unroll
+            for (int k = 0; k < NRD; ++k) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+            constexpr int PER = (NMF - NRD) / (LOADS + 1);
+#pragma unroll
+            for (int k = 0; k < LOADS; ++k) {
+                __builtin_amdgcn_sched_group_barrier(0x008, PER, 0);
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, NMF - NRD - LOADS * PER, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        // a tile's LAST step when another tile follows: stages that tile's third stage, reads nothing -- the fragments of the next tile's
+        // step 0 are read behind the epilogue (they would occupy 44 registers across it; the read costs ~200 cycles per tile)
+        auto last_step = [&](int lbuf, bf16x8(&ca)[MT], bf16x8(&cb)[NT0]) {
+            wait_vmcnt<(D - 2) * LOADS>();
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            stage(lbuf);
+            mm(ca, cb);
+            constexpr int PER = NMF / (LOADS + 1);
+#pragma unroll
+            for (int k = 0; k < LOADS; ++k) {
+                __builtin_amdgcn_sched_group_barrier(0x008, PER, 0);
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, NMF - LOADS * PER, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        // steady-state step: stage k+1 has landed when all but the youngest LOADS VMEM operations are done
+        auto step = [&](int rbuf, int lbuf, bf16x8(&ca)[MT], bf16x8(&cb)[NT0], bf16x8(&na)[MT], bf16x8(&nb)[NT0]) {
+            wait_vmcnt<(D - 2) * LOADS>();
+            body(rbuf, lbuf, ca, cb, na, nb);
+        };
+        // the first two steps behind an epilogue: its NS stores sit between the stages in the (in-order) VMEM queue and may stay in flight
+        // (nst = channel tiles of this wave that exist: a ragged last channel tile issues fewer stores -- a wave-uniform number)
+        auto step_x = [&](int nst, int rbuf, int lbuf, bf16x8(&ca)[MT], bf16x8(&cb)[NT0], bf16x8(&na)[MT], bf16x8(&nb)[NT0]) {
+            // stores of the last epilogue: pooled NTG (one per column), else NTG per PAIR of channel tiles that exists
+            if (nst == 0) wait_vmcnt<(D - 2) * LOADS>();
+            else if (POOL || nst <= 2) wait_vmcnt<(D - 2) * LOADS + NTG>();
+            else wait_vmcnt<(D - 2) * LOADS + 2 * NTG>();
+            body(rbuf, lbuf, ca, cb, na, nb);
+        };
+        // ---- epilogue of one tile, from the accumulator registers (lane: pixel column lane & 15, channels 4 * (lane >> 4) + r)
+        auto epilogue = [&](int tb, int co0, int nvi) {
+            const int lane = fresh_lane();
+            const int g4 = (lane >> 4) * 4;
+            const unsigned *tb_ = tab + tb * 1024;
+            const float *st = stash + wave * 64;
+            const float slope = p.slope;
+            if constexpr (POOL) {
+                const int e = lane & 3;
+                // bias of the channel tile this lane stores (tile e of the wave's four)
+                const f32x4 bs = *reinterpret_cast<const f32x4 *>(st + e * 16 + g4);
+                const unsigned chb = (unsigned)((co0 + wco * 64 + e * 16 + g4) * 2);
+#pragma unroll
+                for (int j = 0; j < NTG; ++j) {
+                    const unsigned ob = tb_[(px_lo + j * 16 + (lane & 15)) * 4 + 1] + chb;
+                    f32x4 sel = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+                    for (int i = 0; i < MT; ++i) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float m = quad_max(acc[i][j][r]);
+                            sel[r] = (e == i) ? m : sel[r];
+                        }
+                        acc[i][j] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+                    }
+                    float v[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float t = sel[r] + bs[r];
+                        v[r] = (p.epilogue == YOLO_EPI_BIAS_LRELU && t < 0.0f) ? t * slope : t;
+                    }
+                    const unsigned lo = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
+                    const unsigned hi = (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
+                    if (e < nvi) store8<0>(p.out, ob, lo, hi);        // (issued once per column by every wave with nvi > 0)
+                }
+            } else {
+                // Two channel tiles (i0, i0 + 1) at a time: after swapping rows 1 / 3 of tile i0's registers with rows 0 / 2 of tile
+                // i0 + 1's, a lane of row g holds EIGHT consecutive channels -- of tile i0 + (g & 1), channels 8 * (g >> 1) .. + 7 -- of
+                // its pixel: 16-byte stores (64 contiguous bytes per pixel and instruction), half as many as 8-byte ones; the 8-byte
+                // form took 9-13 k cycles per tile, bound by store issue (in-kernel stamps).
+                const int g = lane >> 4;
+                const int cl = (g & 1) * 16 + (g >> 1) * 8;                 // first channel of this lane inside a pair of tiles
+                f32x4 bs[2][2];
+#pragma unroll
+                for (int pr = 0; pr < 2; ++pr) {
+                    bs[pr][0] = *reinterpret_cast<const f32x4 *>(st + pr * 32 + cl);
+                    bs[pr][1] = *reinterpret_cast<const f32x4 *>(st + pr * 32 + cl + 4);
+                }
+                const unsigned chb = (unsigned)((co0 + wco * 64 + cl) * 2);
+                const int my_tile = g & 1;                                   // + 2 * pair: the channel tile this lane stores
+                const bool lrelu = p.epilogue == YOLO_EPI_BIAS_LRELU;
+#pragma unroll
+                for (int j = 0; j < NTG; ++j) {
+                    const unsigned slot4 = (unsigned)(px_lo + j * 16 + (lane & 15)) * 4;
+                    const unsigned ob = tb_[slot4 + 1] + chb;
+                    uint4 ax[2];
+                    if constexpr (DGRAD) {
+                        const char *ap = reinterpret_cast<const char *>(p.aux) + (unsigned long)(tb_[slot4 + 2] + chb);
+                        ax[0] = *reinterpret_cast<const uint4 *>(ap);
+                        ax[1] = *reinterpret_cast<const uint4 *>(ap + 64);
+                    }
+#pragma unroll
+                    for (int pr = 0; pr < 2; ++pr) {
+                        float v[8];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            float x = acc[2 * pr][j][r], y = acc[2 * pr + 1][j][r];
+                            row_swap(x, y);
+                            v[r] = x;
+                            v[4 + r] = y;
+                        }
+                        acc[2 * pr][j] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+                        acc[2 * pr + 1][j] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+                        if constexpr (DGRAD) {
+                            const unsigned yy[4] = {ax[pr].x, ax[pr].y, ax[pr].z, ax[pr].w};
+#pragma unroll
+                            for (int k = 0; k < 8; ++k) {
+                                const float a = __uint_as_float((k & 1) ? (yy[k >> 1] & 0xffff0000u) : (yy[k >> 1] << 16));
+                                v[k] = a > 0.0f ? v[k] : v[k] * slope;
+                            }
+                        } else {
+#pragma unroll
+                            for (int k = 0; k < 8; ++k) {
+                                const float t = v[k] + bs[pr][k >> 2][k & 3];
+                                v[k] = lrelu ? fmaxf(t, t * slope) : t;      // LeakyReLU for 0 <= slope <= 1 (host-checked)
+                            }
+                        }
+                        const unsigned w0 = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
+                        const unsigned w1 = (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
+                        const unsigned w2 = (unsigned)f32_to_bf16(v[4]) | ((unsigned)f32_to_bf16(v[5]) << 16);
+                        const unsigned w3 = (unsigned)f32_to_bf16(v[6]) | ((unsigned)f32_to_bf16(v[7]) << 16);
+                        if (2 * pr + my_tile < nvi) {        // (ragged last channel tile: issued by the wave iff 2 * pr < nvi)
+                            if (pr == 0) store16<0>(p.out, ob, w0, w1, w2, w3);
+                            else store16<64>(p.out, ob, w0, w1, w2, w3);
+                        }
+                    }
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        };
+
+        rd(0, a0, b0);
+        int rbuf = 1, lbuf = D;
+        auto adv = [&]() {
+            rbuf = rbuf + 1 == NST ? 0 : rbuf + 1;
+            lbuf = lbuf + 1 == NST ? 0 : lbuf + 1;
+        };
+        // ONE loop body for every tile, no branch with MFMAs in its arms (at ~250 live registers hipcc answers such a branch by
+        // spilling the accumulators around it): behind the workgroup's last tile the three boundary steps stage that tile's own first
+        // stages once more -- 96 KB nobody reads; the kernel drains them before it ends.
+        int nst = 0;                                        // stores of the previous epilogue, in channel tiles (0: none yet)
+        for (int ti = 0; ti < n_mine; ++ti) {
+            const int tn = ti + 1 < n_mine ? ti + 1 : ti;
+            int co0_next;
+            unsigned px0_next;
+            tile_of(tn, co0_next, px0_next);
+            step_x(nst, rbuf, lbuf, a0, b0, a1, b1);        // step 0
+            adv();
+            // every wave is past the previous tile's epilogue (barrier of step 0): its table buffer is free for tile ti + 1
+            build_table((ti + 1) & 1, px0_next);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the table is in LDS before this wave arrives at the next barrier
+            step_x(nst, rbuf, lbuf, a1, b1, a0, b0);        // step 1
+            adv();
+            for (int it = 2; it + 4 < nk; it += 2) {
+                step(rbuf, lbuf, a0, b0, a1, b1);
+                adv();
+                step(rbuf, lbuf, a1, b1, a0, b0);
+                adv();
+            }
+            step(rbuf, lbuf, a0, b0, a1, b1);               // step nk-4: stages the tile's last stage
+            adv();
+            // the next tile's first D stages ride under this tile's last D steps
+            load_b_voff((ti + 1) & 1);
+            stage_reset(co0_next);
+            step(rbuf, lbuf, a1, b1, a0, b0);               // step nk-3
+            adv();
+            step(rbuf, lbuf, a0, b0, a1, b1);               // step nk-2
+            adv();
+            last_step(lbuf, a1, b1);                        // step nk-1
+            adv();
+#ifdef IGEMM_STAMPS
+            if (ti == 0) PSTAMP(2);
+            if (ti == 1) PSTAMP(4);
+            if (ti == n_mine - 1) PSTAMP(6);
+#endif
+            // channel tiles (of 16) this wave holds inside Cout: 4 but for a ragged last tile (Cout % 16 == 0, host-checked)
+            nst = __builtin_amdgcn_readfirstlane(min(4, max(0, (p.Cout - co0_cur - wco * 64) >> 4)));
+            epilogue(ti & 1, co0_cur, nst);
+#ifdef IGEMM_STAMPS
+            if (ti == 0) PSTAMP(3);
+            if (ti == 1) PSTAMP(5);
+#endif
+            // fragments of the next tile's step 0: its stage landed (wait of step nk-1) and is visible (barrier of step nk-1)
+            rd(rbuf == 0 ? NST - 1 : rbuf - 1, a0, b0);
+            if (co0_next != co0_cur) load_stash(co0_next);  // (the same wave writes and reads its stash: in order)
+            co0_cur = co0_next;
+        }
+        wait_vmcnt<0>();                                    // no LDS-DMA may outlive the workgroup
+    };
+    if (grp == 0) run(std::integral_constant<int, NT0>{});
+    else run(std::integral_constant<int, NT1>{});
+#ifdef IGEMM_STAMPS
+    if (p.dbg && lane == 0 && blockIdx.x < 512) {
+        tstamp[7] = __builtin_amdgcn_s_memtime();
+#pragma unroll
+        for (int i = 0; i < 8; ++i) p.dbg[((long)blockIdx.x * 8 + wave) * 8 + i] = tstamp[i];
+    }
+#endif
+#undef PSTAMP
+}
+
+static void magic_u31(unsigned d, unsigned &magic, unsigned &shift)
+{
+    // floor(n / d) = umulhi(n, magic) >> shift for every n < 2^31 (Granlund & Montgomery; magic = ceil(2^(31+l) / d), l = ceil(log2 d))
+    if (d <= 1) { magic = 0; shift = 0; return; }
+    unsigned l = 0;
+    while ((1ull << l) < d) ++l;
+    const unsigned long long num = 1ull << (31 + l);
+    magic = (unsigned)((num + d - 1) / d);
+    shift = l - 1;
+}
+
+template <int NTILES, bool POOL, bool DGRAD>
+static int persist_launch(const IgemmParams &p, hipStream_t s)
+{
+    using C = PersistCfg<NTILES>;
+    static bool attr_done[64] = {};
+    static int cus[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    if (!attr_done[dev]) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&igemm_persist_kernel<NTILES, POOL, DGRAD>), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+        if (e != hipSuccess) return fail((int)e, "yolo_igemm: hipFuncSetAttribute(%d B LDS): %s", C::LDS_BYTES, hipGetErrorString(e));
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        cus[dev] = n;
+        attr_done[dev] = true;
+    }
+    IgemmParams q = p;
+    q.n_co_tiles = (p.Cout + C::TCO - 1) / C::TCO;
+    if (POOL) q.tpx_valid = C::TPX;
+    if (q.tpx_valid <= 0 || q.tpx_valid > C::TPX) q.tpx_valid = C::TPX;
+    q.n_px_tiles = (int)((p.M + q.tpx_valid - 1) / q.tpx_valid);
+    q.nk = (int)(p.Ktot / C::BK);
+    if (p.px_fastest < 0) q.px_fastest = 0;
+    magic_u31((unsigned)p.HoWo, q.div_hw_magic, q.div_hw_shift);
+    magic_u31((unsigned)p.Wo, q.div_w_magic, q.div_w_shift);
+    magic_u31((unsigned)p.Wo / 2, q.div_hw2_magic, q.div_hw2_shift);
+    const long tiles = (long)q.n_co_tiles * q.n_px_tiles;
+    const int G = (int)std::min<long>(tiles, cus[dev]);
+    hipLaunchKernelGGL((igemm_persist_kernel<NTILES, POOL, DGRAD>), dim3(G), dim3(C::NTHR), C::LDS_BYTES, s, q);
+    return check_launch("yolo_igemm (persistent)");
+}
+
+int igemm_persist_launch(const IgemmParams &p, int hint, int splits, hipStream_t s)
+{
+    if (p.stats || p.w_blocked || splits > 1 || p.slab_stride || p.out_fp32 || p.px_begin)
+        return fail(YOLO_E_UNSUPPORTED, "yolo_igemm: tile_hint %d is a plain bf16 launch (no bn_stats, blocked weights, split-K, fp32 output, pixel range)", hint);
+    if (p.tap_len % 32) return fail(YOLO_E_UNSUPPORTED, "yolo_igemm: tile_hint %d needs tap_len %% 32 == 0", hint);
+    const long nk = p.Ktot / 32;
+    if (nk % 2 || nk < 6) return fail(YOLO_E_UNSUPPORTED, "yolo_igemm: tile_hint %d needs an even number (>= 6) of 32-deep K steps", hint);
+    if (p.epilogue != YOLO_EPI_NONE && p.epilogue != YOLO_EPI_BIAS && p.epilogue != YOLO_EPI_BIAS_LRELU && p.epilogue != YOLO_EPI_MUL_DLRELU)
+        return fail(YOLO_E_UNSUPPORTED, "yolo_igemm: tile_hint %d has no epilogue %d", hint, p.epilogue);
+    if (!(p.slope >= 0.0f && p.slope <= 1.0f)) return fail(YOLO_E_UNSUPPORTED, "yolo_igemm: tile_hint %d needs 0 <= slope <= 1", hint);
+    if (p.Cout > 256 && p.Cout % 256) return fail(YOLO_E_UNSUPPORTED, "yolo_igemm: tile_hint %d needs Cout <= 256 or Cout %% 256 == 0", hint);
+    if (p.Cout % 16) return fail(YOLO_E_UNSUPPORTED, "yolo_igemm: tile_hint %d needs Cout %% 16 == 0", hint);
+    if (p.M >= (1L << 31)) return fail(YOLO_E_UNSUPPORTED, "yolo_igemm: tile_hint %d indexes fewer than 2^31 output pixels", hint);
+    // every operand is addressed as base + 32-bit byte offset
+    const long n_img = p.M / p.HoWo + 1;
+    const long in_bytes = (n_img * p.in_img_stride + (long)p.KH * p.in_row_stride) * 2, w_bytes = (long)p.Cout * p.Ktot * 2;
+    const long out_bytes = (n_img * p.out_img_stride + p.out_off) * 2, aux_bytes = p.aux ? (n_img * p.aux_img_stride + p.aux_off) * 2 : 0;
+    if (in_bytes >= (1L << 32) || w_bytes >= (1L << 32) || out_bytes >= (1L << 32) || aux_bytes >= (1L << 32))
+        return fail(YOLO_E_UNSUPPORTED, "yolo_igemm: tile_hint %d addresses operands below 4 GB", hint);
+    if ((p.out_off | p.out_px_stride | p.out_row_stride) & 3 || (p.out_img_stride & 3))
+        return fail(YOLO_E_UNSUPPORTED, "yolo_igemm: tile_hint %d stores 8-byte pieces: output strides in multiples of 4 elements", hint);
+    if (p.epilogue == YOLO_EPI_MUL_DLRELU && ((p.aux_off | p.aux_px_stride | p.aux_row_stride) & 3 || (p.aux_img_stride & 3)))
+        return fail(YOLO_E_UNSUPPORTED, "yolo_igemm: tile_hint %d reads aux in 8-byte pieces", hint);
+    if (p.pool) {
+        if (hint != 21 || p.pool != 1 || !(p.Wo == 112 || p.Wo == 56 || p.Wo == 28) || (p.HoWo / p.Wo) % 2 || p.M % 224
+            || (p.epilogue != YOLO_EPI_BIAS && p.epilogue != YOLO_EPI_BIAS_LRELU))
+            return fail(YOLO_E_UNSUPPORTED, "yolo_igemm: the pooled epilogue of tile_hint 21 needs pool2 = 1, rows of 112, 56 or 28 pixels and whole 224-pixel tiles");
+        return persist_launch<14, true, false>(p, s);
+    }
+    const bool dg = p.epilogue == YOLO_EPI_MUL_DLRELU;
+    switch (hint) {
+    case 20: return dg ? persist_launch<13, false, true>(p, s) : persist_launch<13, false, false>(p, s);
+    case 21: return dg ? persist_launch<14, false, true>(p, s) : persist_launch<14, false, false>(p, s);
+    }
+    return fail(YOLO_E_ARG, "yolo_igemm: tile_hint %d is not a persistent configuration", hint);
+}
+
+}  // namespace yolo

@@ -186,7 +186,8 @@ def _flush_caches(dev):
 
 # tile edge (co, px slots) of the configurations the tuner may combine
 _TILE = {1: (128, 128), 3: (128, 64), 4: (64, 128), 5: (128, 128), 10: (64, 128), 11: (256, 128), 12: (256, 256), 13: (256, 128), 14: (256, 208),
-         15: (256, 208), 16: (256, 224), 17: (128, 208), 18: (128, 224), 19: (64, 16)}      # (19: the streaming 1x1 kernel works in 16-pixel groups)
+         15: (256, 208), 16: (256, 224), 17: (128, 208), 18: (128, 224), 19: (64, 16),       # (19: the streaming 1x1 kernel works in 16-pixel groups)
+         20: (256, 208), 21: (256, 224)}                                                     # persistent kernels (igemm_persist.hip)
 _TAIL_CANDIDATES = (5, 3, 4)
 # (workgroup slots of the chip, relative time of one tile) per configuration, for _default_plan: 8-wave configurations run
 # one workgroup per CU, the 4-wave ones two; times are relative to a 256x256 tile and follow the measured in-tile rates
@@ -232,6 +233,14 @@ def _pipe_ok(d: IgemmDesc) -> bool:
     return d.tap_len % 32 == 0 and nk % 2 == 0 and nk >= 4 and not d.bn_stats and not d.w_blocked
 
 
+def _persist_ok(d: IgemmDesc) -> bool:
+    """the persistent kernels (tile_hint 20 / 21: one software pipeline over all tiles of a workgroup, epilogue out of the accumulator
+    registers) take the problem: an even number >= 6 of 32-deep K steps, whole 256-channel tiles (or one ragged tile), bf16 output"""
+    nk = d.KH * d.KW * d.tap_len // 32
+    return (d.tap_len % 32 == 0 and nk % 2 == 0 and nk >= 6 and not d.bn_stats and not d.w_blocked and not d.out_fp32 and d.split_k <= 1
+            and (d.Cout <= 256 or d.Cout % 256 == 0) and d.Cout % 16 == 0 and d.epilogue in (EPI_NONE, EPI_BIAS, EPI_BIAS_LRELU, EPI_MUL_DLRELU))
+
+
 def _pipe_pool_ok(d: IgemmDesc) -> bool:
     """... and their pooled epilogue (224-pixel tiles of whole row pairs) the output geometry"""
     return _pipe_ok(d) and d.Wo in (112, 56, 28) and d.Ho % 2 == 0 and (d.Ho * d.Wo) % 112 == 0 and d.Cout % 8 == 0
@@ -268,6 +277,10 @@ def _run_plan_igemm(L_, d: IgemmDesc, plan, inp, w, bias, aux, out, st, what):
     if d.bn_stats and (plan[0] in ("splitk", "slabs") or (isinstance(plan[0], int) and len(plan) == 4)):
         # a launch that also accumulates BatchNorm statistics must be one plain launch: keep the plan's main configuration
         plan = (plan[1], 1) if plan[0] in ("splitk", "slabs") else (plan[0], plan[1])
+    if plan[0] == "tile" and plan[1] in (20, 21) and (d.pool2 in (2, 3) or not _persist_ok(d)):
+        # the persistent kernels pool for inference only (pool2 = 1): training's pooled map + un-pooled activation / arg-max codes, and
+        # anything else they do not take (a plan measured for pool2 = 1 also serves pool2 = 3, see _tune_key), run the pipelined kernels
+        plan = ("tile", 16 if (d.pool2 or plan[1] == 21) else 15, plan[2], 0 if d.pool2 else plan[3]) + tuple(plan[4:])
     if d.bn_stats:      # the pipelined kernels (15 .. 18) have no statistics epilogue: the staggered 256 x 208 loop takes their place
         if plan[0] == "tile" and plan[1] in (15, 16, 17, 18):
             plan = ("tile", 14, plan[2], min(plan[3], 208)) + tuple(plan[4:])
@@ -374,9 +387,14 @@ def _tune(L_, d: IgemmDesc, inp, w, bias, aux, out, st, what):
                 if (d.Ho * d.Wo) % 112 == 0:
                     consider(("tile", 16, o, 0))        # 224-pixel tiles
                     consider(("tile", 18, o, 0))
+            if _persist_ok(d):
+                for tp in sorted({tile_px, 208, 0 if M % 224 else 224} - {0}):      # persistent loop: whole rounds matter less, full tiles more
+                    consider(("tile", 21 if tp == 224 else 20, o, tp))
     elif _pipe_pool_ok(d):
         consider(("tile", 16, 1, 0))                    # MaxPool2d(2,2) fused into the pipelined kernels' epilogue
         consider(("tile", 18, 1, 0))
+        if _persist_ok(d) and d.pool2 == 1 and M % 224 == 0:
+            consider(("tile", 21, 1, 0))                # ... and into the persistent kernel's register epilogue (quad-permute max)
     # tail plans: the two fastest large-tile configurations, cut where their tiles stop filling whole rounds of
     # 256 (one workgroup per CU) or 512 slots, remainder with a small tile
     if times and not d.pool2:
