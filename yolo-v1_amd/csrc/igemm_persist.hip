@@ -56,13 +56,35 @@ __device__ __forceinline__ int fresh_lane()
     return l;
 }
 
-__device__ __forceinline__ float quad_max(float v)
+// Maximum over the four lanes of a quad, for the four values of one accumulator tile: v_max_f32 with a DPP operand (quad_perm
+// [1,0,3,2], then [2,3,0,1]) -- two instructions per value.  (Through fmaxf + __builtin_amdgcn_update_dpp hipcc emits a v_mov_dpp
+// and two canonicalising self-maxima per step: six.)  The four chains are interleaved, so a DPP operand is always at least three
+// instructions old (the ISA asks for two wait states between a VALU write and a DPP read of the same register); the leading s_nop
+// covers whatever instruction wrote the inputs.
+__device__ __forceinline__ f32x4 quad_max4(f32x4 v)
 {
-    // maximum over the four lanes of a quad: quad_perm [1,0,3,2] then [2,3,0,1]
-    const float a = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
-    const float m = fmaxf(v, a);
-    const float b = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, m), 0x4E, 0xF, 0xF, true));
-    return fmaxf(m, b);
+    float a0, a1, a2, a3;
+    asm volatile("s_nop 1\n\t"
+                 "v_max_f32_dpp %0, %4, %4 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                 "v_max_f32_dpp %1, %5, %5 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                 "v_max_f32_dpp %2, %6, %6 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                 "v_max_f32_dpp %3, %7, %7 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                 "v_max_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+                 "v_max_f32_dpp %1, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+                 "v_max_f32_dpp %2, %2, %2 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+                 "v_max_f32_dpp %3, %3, %3 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf"
+                 : "=&v"(a0), "=&v"(a1), "=&v"(a2), "=&v"(a3)
+                 : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]));
+    return f32x4{a0, a1, a2, a3};
+}
+
+// two floats -> packed bf16 (round to nearest even, NaN stays NaN): ONE v_cvt_pk_bf16_f32 (casting the floats one by one costs a
+// conversion each plus a shift and an or)
+__device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi)
+{
+    unsigned r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
 }
 
 // 8-byte store: scalar base + 32-bit byte offset per lane + immediate.  Inline asm: exactly one VMEM instruction per call, whatever
@@ -72,7 +94,7 @@ __device__ __forceinline__ void store8(const void *base, unsigned voff, unsigned
 {
     typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
     const u32x2 d = {lo, hi};
-    asm volatile("global_store_dwordx2 %0, %1, %2 offset:%3" ::"v"(voff), "v"(d), "s"(base), "n"(IMM) : "memory");
+    asm volatile("global_store_dwordx2 %0, %1, %2 offset:%3\n\ts_nop 1" ::"v"(voff), "v"(d), "s"(base), "n"(IMM) : "memory");
 }
 
 // DGRAD: the instantiation whose epilogue multiplies by LeakyReLU'(aux) (its 56 registers of aux vectors stay out of the others)
@@ -81,16 +103,28 @@ __device__ __forceinline__ void store16(const void *base, unsigned voff, unsigne
 {
     typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
     const u32x4 v = {a, b, c, d};
-    asm volatile("global_store_dwordx4 %0, %1, %2 offset:%3" ::"v"(voff), "v"(v), "s"(base), "n"(IMM) : "memory");
+    // (s_nop: a store of more than 64 bits reads its data registers for a cycle after issue, and the compiler, which pads that hazard
+    // for its own stores, does not look into inline assembly: the next VALU instruction could overwrite them)
+    asm volatile("global_store_dwordx4 %0, %1, %2 offset:%3\n\ts_nop 1" ::"v"(voff), "v"(v), "s"(base), "n"(IMM) : "memory");
 }
 
-// v_permlane16_swap_b32: rows (16 lanes) 1 and 3 of x change places with rows 0 and 2 of y
-__device__ __forceinline__ void row_swap(float &x, float &y)
+// v_permlane16_swap_b32 x, y: rows (16 lanes) 1 and 3 of x change places with rows 0 and 2 of y -- for the four registers of two
+// accumulator tiles at once.  Inline assembly: through __builtin_amdgcn_permlane16_swap hipcc (ROCm 7.2) used the instruction's FIRST
+// result for both outputs once the inputs were dead behind it (seen in the ISA; half of every 16-byte store was wrong).
+__device__ __forceinline__ void row_swap4(f32x4 &x, f32x4 &y)
 {
-    typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
-    const u32x2 r = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, x), __builtin_bit_cast(unsigned, y), false, false);
-    x = __builtin_bit_cast(float, r.x);
-    y = __builtin_bit_cast(float, r.y);
+    float x0 = x[0], x1 = x[1], x2 = x[2], x3 = x[3], y0 = y[0], y1 = y[1], y2 = y[2], y3 = y[3];
+    // (s_nop in front: a VALU write of an operand -- the compiler's register copies -- must be two wait states old; behind: the same for
+    // the consumers; the compiler pads neither around inline assembly)
+    asm volatile("s_nop 1\n\t"
+                 "v_permlane16_swap_b32 %0, %4\n\t"
+                 "v_permlane16_swap_b32 %1, %5\n\t"
+                 "v_permlane16_swap_b32 %2, %6\n\t"
+                 "v_permlane16_swap_b32 %3, %7\n\t"
+                 "s_nop 1"
+                 : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(y0), "+v"(y1), "+v"(y2), "+v"(y3));
+    x = f32x4{x0, x1, x2, x3};
+    y = f32x4{y0, y1, y2, y3};
 }
 
 template <int NTILES, bool POOL, bool DGRAD>
@@ -228,11 +262,7 @@ __global__ void __launch_bounds__(512, 2) igemm_persist_kernel(const IgemmParams
     const int a_rd0 = lds_off<BK, true>(wco * 64 + (lane & 15), lane >> 4);
     const int b_rd0 = A_BYTES + lds_off<BK, true>(px_lo + (lane & 15), lane >> 4);
 
-    f32x4 acc[MT][NT0];
-#pragma unroll
-    for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int j = 0; j < NT0; ++j) acc[i][j] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    f32x4 acc[MT][NT0];      // (never zero-filled: the MFMAs of a tile's step 0 take the constant 0 as their C operand)
 
     // ---- prologue: table + bias stash of tile 0, its first D stages in flight, stage 0 landed and visible
     int co0_cur;
@@ -266,19 +296,23 @@ __global__ void __launch_bounds__(512, 2) igemm_persist_kernel(const IgemmParams
 #pragma unroll
             for (int j = 0; j < NTG; ++j) bfr[j] = *reinterpret_cast<const bf16x8 *>(sb + b_rd0 + j * 1024);
         };
-        auto mm = [&](bf16x8(&af)[MT], bf16x8(&bfr)[NT0]) {
+        auto mm = [&](auto zc, bf16x8(&af)[MT], bf16x8(&bfr)[NT0]) {
+            constexpr bool Z = decltype(zc)::value;           // a tile's first step: C = 0 (inline constant), no accumulator to clear
 #pragma unroll
             for (int i = 0; i < MT; ++i)
 #pragma unroll
-                for (int j = 0; j < NTG; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < NTG; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], Z ? f32x4{0.0f, 0.0f, 0.0f, 0.0f} : acc[i][j], 0, 0, 0);
         };
+        using ZeroC = std::integral_constant<bool, true>;
+        using AccC = std::integral_constant<bool, false>;
         constexpr int NRD = MT + NTG, NMF = MT * NTG;
-        auto body = [&](int rbuf, int lbuf, bf16x8(&ca)[MT], bf16x8(&cb)[NT0], bf16x8(&na)[MT], bf16x8(&nb)[NT0]) {
+        auto body = [&](auto zc, int rbuf, int lbuf, bf16x8(&ca)[MT], bf16x8(&cb)[NT0], bf16x8(&na)[MT], bf16x8(&nb)[NT0]) {
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
             rd(rbuf, na, nb);
             stage(lbuf);
-            mm(ca, cb);
+            mm(zc, ca, cb);
 #pragma unroll
             for (int k = 0; k < NRD; ++k) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -300,7 +334,7 @@ __global__ void __launch_bounds__(512, 2) igemm_persist_kernel(const IgemmParams
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
             stage(lbuf);
-            mm(ca, cb);
+            mm(AccC{}, ca, cb);
             constexpr int PER = NMF / (LOADS + 1);
 #pragma unroll
             for (int k = 0; k < LOADS; ++k) {
@@ -313,19 +347,22 @@ __global__ void __launch_bounds__(512, 2) igemm_persist_kernel(const IgemmParams
         // steady-state step: stage k+1 has landed when all but the youngest LOADS VMEM operations are done
         auto step = [&](int rbuf, int lbuf, bf16x8(&ca)[MT], bf16x8(&cb)[NT0], bf16x8(&na)[MT], bf16x8(&nb)[NT0]) {
             wait_vmcnt<(D - 2) * LOADS>();
-            body(rbuf, lbuf, ca, cb, na, nb);
+            body(AccC{}, rbuf, lbuf, ca, cb, na, nb);
         };
         // the first two steps behind an epilogue: its NS stores sit between the stages in the (in-order) VMEM queue and may stay in flight
         // (nst = channel tiles of this wave that exist: a ragged last channel tile issues fewer stores -- a wave-uniform number)
-        auto step_x = [&](int nst, int rbuf, int lbuf, bf16x8(&ca)[MT], bf16x8(&cb)[NT0], bf16x8(&na)[MT], bf16x8(&nb)[NT0]) {
+        auto step_x = [&](auto zc, int nst, int rbuf, int lbuf, bf16x8(&ca)[MT], bf16x8(&cb)[NT0], bf16x8(&na)[MT], bf16x8(&nb)[NT0]) {
             // stores of the last epilogue: pooled NTG (one per column), else NTG per PAIR of channel tiles that exists
             if (nst == 0) wait_vmcnt<(D - 2) * LOADS>();
             else if (POOL || nst <= 2) wait_vmcnt<(D - 2) * LOADS + NTG>();
             else wait_vmcnt<(D - 2) * LOADS + 2 * NTG>();
-            body(rbuf, lbuf, ca, cb, na, nb);
+            body(zc, rbuf, lbuf, ca, cb, na, nb);
         };
         // ---- epilogue of one tile, from the accumulator registers (lane: pixel column lane & 15, channels 4 * (lane >> 4) + r)
         auto epilogue = [&](int tb, int co0, int nvi) {
+            // (the accumulators were written by the MFMAs just issued: the compiler's hazard handling does not look into the inline
+            // assembly that reads them first -- give the matrix pipe its worst-case drain time)
+            asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
             const int lane = fresh_lane();
             const int g4 = (lane >> 4) * 4;
             const unsigned *tb_ = tab + tb * 1024;
@@ -342,12 +379,9 @@ __global__ void __launch_bounds__(512, 2) igemm_persist_kernel(const IgemmParams
                     f32x4 sel = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
                     for (int i = 0; i < MT; ++i) {
+                        const f32x4 m = quad_max4(acc[i][j]);
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const float m = quad_max(acc[i][j][r]);
-                            sel[r] = (e == i) ? m : sel[r];
-                        }
-                        acc[i][j] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+                        for (int r = 0; r < 4; ++r) sel[r] = (e == i) ? m[r] : sel[r];
                     }
                     float v[4];
 #pragma unroll
@@ -355,8 +389,7 @@ __global__ void __launch_bounds__(512, 2) igemm_persist_kernel(const IgemmParams
                         const float t = sel[r] + bs[r];
                         v[r] = (p.epilogue == YOLO_EPI_BIAS_LRELU && t < 0.0f) ? t * slope : t;
                     }
-                    const unsigned lo = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
-                    const unsigned hi = (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
+                    const unsigned lo = pack_bf16x2(v[0], v[1]), hi = pack_bf16x2(v[2], v[3]);
                     if (e < nvi) store8<0>(p.out, ob, lo, hi);        // (issued once per column by every wave with nvi > 0)
                 }
             } else {
@@ -387,16 +420,9 @@ __global__ void __launch_bounds__(512, 2) igemm_persist_kernel(const IgemmParams
                     }
 #pragma unroll
                     for (int pr = 0; pr < 2; ++pr) {
-                        float v[8];
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            float x = acc[2 * pr][j][r], y = acc[2 * pr + 1][j][r];
-                            row_swap(x, y);
-                            v[r] = x;
-                            v[4 + r] = y;
-                        }
-                        acc[2 * pr][j] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-                        acc[2 * pr + 1][j] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+                        f32x4 x = acc[2 * pr][j], y = acc[2 * pr + 1][j];
+                        row_swap4(x, y);
+                        float v[8] = {x[0], x[1], x[2], x[3], y[0], y[1], y[2], y[3]};
                         if constexpr (DGRAD) {
                             const unsigned yy[4] = {ax[pr].x, ax[pr].y, ax[pr].z, ax[pr].w};
 #pragma unroll
@@ -411,10 +437,7 @@ __global__ void __launch_bounds__(512, 2) igemm_persist_kernel(const IgemmParams
                                 v[k] = lrelu ? fmaxf(t, t * slope) : t;      // LeakyReLU for 0 <= slope <= 1 (host-checked)
                             }
                         }
-                        const unsigned w0 = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
-                        const unsigned w1 = (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
-                        const unsigned w2 = (unsigned)f32_to_bf16(v[4]) | ((unsigned)f32_to_bf16(v[5]) << 16);
-                        const unsigned w3 = (unsigned)f32_to_bf16(v[6]) | ((unsigned)f32_to_bf16(v[7]) << 16);
+                        const unsigned w0 = pack_bf16x2(v[0], v[1]), w1 = pack_bf16x2(v[2], v[3]), w2 = pack_bf16x2(v[4], v[5]), w3 = pack_bf16x2(v[6], v[7]);
                         if (2 * pr + my_tile < nvi) {        // (ragged last channel tile: issued by the wave iff 2 * pr < nvi)
                             if (pr == 0) store16<0>(p.out, ob, w0, w1, w2, w3);
                             else store16<64>(p.out, ob, w0, w1, w2, w3);
@@ -440,12 +463,12 @@ __global__ void __launch_bounds__(512, 2) igemm_persist_kernel(const IgemmParams
             int co0_next;
             unsigned px0_next;
             tile_of(tn, co0_next, px0_next);
-            step_x(nst, rbuf, lbuf, a0, b0, a1, b1);        // step 0
+            step_x(ZeroC{}, nst, rbuf, lbuf, a0, b0, a1, b1);        // step 0
             adv();
             // every wave is past the previous tile's epilogue (barrier of step 0): its table buffer is free for tile ti + 1
             build_table((ti + 1) & 1, px0_next);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the table is in LDS before this wave arrives at the next barrier
-            step_x(nst, rbuf, lbuf, a1, b1, a0, b0);        // step 1
+            step_x(AccC{}, nst, rbuf, lbuf, a1, b1, a0, b0);         // step 1
             adv();
             for (int it = 2; it + 4 < nk; it += 2) {
                 step(rbuf, lbuf, a0, b0, a1, b1);
