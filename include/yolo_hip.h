@@ -29,7 +29,7 @@ extern "C" {
 #endif
 
 /* 2: yolo_igemm_desc gained tile_px / split_slabs, yolo_wgrad_desc gained dw_sumsq / slabs / slab_floats, the multi-tensor Adam entries
- *    gained skip_flag, yolo_conv_stem7_dgrad is new.  A binding must refuse a library whose version differs from the header it was
+ *    gained skip_flag.  A binding must refuse a library whose version differs from the header it was
  *    written against (yolo/_hip.py does): the descriptors are passed by pointer and a shorter struct would be read past its end. */
 #define YOLO_HIP_ABI_VERSION 2
 

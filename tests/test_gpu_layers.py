@@ -644,7 +644,7 @@ def test_streaming_1x1_kernel(cin, cout, epi, stride):
 def _persist_problem(N, cin, cout, k, H, W, epi, pool=0, stride=1):
     """one yolo_igemm problem on random data: (descriptor, input, weight panel, bias, aux, output Act)"""
     from yolo import engine
-    from yolo._hip import EPI_BIAS_LRELU, EPI_MUL_DLRELU, EPI_NONE, IgemmDesc
+    from yolo._hip import EPI_BIAS_ADD_LRELU, EPI_BIAS_LRELU, EPI_MUL_DLRELU, EPI_NONE, IgemmDesc
     g = torch.Generator(device="cuda").manual_seed(1000 * cin + cout + k)
     pad = (k - 1) // 2
     a_in = engine.Act(N, H, W, cin, 1, "cuda")
@@ -661,13 +661,14 @@ def _persist_problem(N, cin, cout, k, H, W, epi, pool=0, stride=1):
     d.stride, d.KH, d.KW, d.tap_len, d.Cout = stride, k, k, cin, cout
     d.out_img_stride, d.out_row_stride, d.out_px_stride, d.out_off = a_out.img_stride, a_out.row_stride, a_out.px_stride, a_out.interior_off()
     d.aux_img_stride, d.aux_row_stride, d.aux_px_stride, d.aux_off = aux.img_stride, aux.row_stride, aux.px_stride, aux.interior_off()
-    d.epilogue = {"lrelu": EPI_BIAS_LRELU, "gate": EPI_MUL_DLRELU, "none": EPI_NONE}[epi]
+    d.epilogue = {"lrelu": EPI_BIAS_LRELU, "gate": EPI_MUL_DLRELU, "none": EPI_NONE, "add": EPI_BIAS_ADD_LRELU}[epi]
     d.slope, d.out_fp32, d.split_k, d.pool2 = 0.1, 0, 1, pool
     return d, a_in, w, b, aux, a_out
 
 
 @pytest.mark.parametrize("cin,cout,k,epi,tpx", [(64, 512, 3, "lrelu", 196), (64, 512, 3, "lrelu", 208), (192, 256, 1, "lrelu", 196), (256, 512, 1, "gate", 196),
-                                                 (128, 256, 3, "gate", 208), (64, 192, 3, "lrelu", 196), (512, 256, 1, "none", 100), (64, 256, 3, "lrelu", 224)])
+                                                 (128, 256, 3, "gate", 208), (64, 192, 3, "lrelu", 196), (512, 256, 1, "none", 100), (64, 256, 3, "lrelu", 224),
+                                                 (256, 1024, 1, "add", 208), (192, 256, 1, "add", 224)])
 def test_persistent_kernel_equals_the_pipelined_one(cin, cout, k, epi, tpx):
     """igemm_persist.hip (tile_hint 20 / 21): several tiles per workgroup in ONE software pipeline (61 440 pixels: 296-615 pixel tiles x
     1-2 channel tiles for 256 workgroups), table of the next tile built under the K loop, epilogue straight out of the accumulator
@@ -680,7 +681,7 @@ def test_persistent_kernel_equals_the_pipelined_one(cin, cout, k, epi, tpx):
 
     def run(pl):
         a_out.t.fill_(7.0)
-        engine._run_plan_igemm(lib(), d, pl, a_in.p, ptr(w), ptr(b) if epi == "lrelu" else None, aux.p if epi == "gate" else None, a_out.p, stream(), "test")
+        engine._run_plan_igemm(lib(), d, pl, a_in.p, ptr(w), ptr(b) if epi in ("lrelu", "add") else None, aux.p if epi in ("gate", "add") else None, a_out.p, stream(), "test")
         return a_out.interior().clone()
 
     ref = run(("tile", 16 if tpx == 224 else 15, 1, 0 if tpx == 224 else tpx))
@@ -709,3 +710,20 @@ def test_persistent_kernel_fuses_the_pool(W, H, cin, cout):
     got = run(("tile", 21, 1, 0))
     assert torch.equal(got, ref), (got.float() - ref.float()).abs().max().item()
     assert torch.equal(a_out.view()[:, 0], torch.full_like(a_out.view()[:, 0], 7.0))
+    # pool2 = 3 (training): pooled map + 2-bit arg-max codes, one uint16 per (pooled pixel, 8 channels) -- map AND codes bit for bit
+    d.pool2 = 3
+    codes = torch.zeros(a_out.t.numel() // 8, dtype=torch.int16, device="cuda")
+
+    def run3(pl):
+        a_out.t.fill_(7.0)
+        codes.fill_(-1)
+        engine._run_plan_igemm(lib(), d, pl, a_in.p, ptr(w), ptr(b), ptr(codes), a_out.p, stream(), "test")
+        return a_out.interior().clone(), codes.clone()
+
+    ref_y, ref_c = run3(("tile", 16, 1, 0))
+    got_y, got_c = run3(("tile", 21, 1, 0))
+    assert torch.equal(ref_y, ref), "pool2 = 3 stores the same pooled map as pool2 = 1"
+    assert torch.equal(got_y, ref_y)
+    assert torch.equal(got_c, ref_c), int((got_c != ref_c).sum())
+    assert int((ref_c != -1).sum()) >= a_out.interior().numel() // 8 - 64   # the interior codes were written (0xffff is a legal code: a few), the rest was not
+    assert int((ref_c != -1).sum()) <= a_out.interior().numel() // 8

@@ -668,3 +668,42 @@ def test_flagged_step_updates_nothing_and_model_reads_wait_for_the_background_up
     m.load_state_dict(sd1)                       # (2): load waits as well
     for k, v in m.state_dict().items():
         assert torch.equal(v, sd1[k])
+
+
+def test_gradient_reaches_the_input_image():
+    """The reference's tests/test_backbone.py:187-196 on the device (the one reference-suite test the HIP path failed with
+    NotImplementedError): YOLOv1()(x).sum().backward() with x.requires_grad leaves a finite, non-zero x.grad -- and the stem's data
+    gradient itself (7x7 / stride 2 / pad 3 as four parity-class correlations, engine.Plan._stem_dgrad) equals stock torch's on two
+    images within the 3-ulp bf16 bound of the other gradient checks, teacher-forced: conv -> LeakyReLU -> MaxPool2d with the same
+    bf16-rounded operands on both sides, so that LeakyReLU gates and pool arg-maxes agree."""
+    import copy
+    import torch.nn as nn
+    from test_gpu_layers import _bf, _close, bf16_faithful
+    from yolo import YOLOv1, engine
+    torch.manual_seed(21)
+    model = YOLOv1().cuda().eval()
+    x = torch.randn(1, 3, 448, 448, device="cuda", requires_grad=True)
+    model(x).sum().backward()
+    assert x.grad is not None and x.grad.shape == x.shape and torch.isfinite(x.grad).all() and float(x.grad.abs().max()) > 0
+    # ... and the parameters got their gradients in the same pass, as before
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in model.parameters())
+    del model
+    # the stem alone against stock torch
+    mods_c = nn.Sequential(nn.Conv2d(3, 64, 7, 2, 3), nn.LeakyReLU(0.1), nn.MaxPool2d(2, 2))
+    mods_g = copy.deepcopy(mods_c).cuda()
+    xs = torch.randn(2, 3, 64, 96)
+    xc = _bf(xs).clone().requires_grad_(True)
+    yc = bf16_faithful(mods_c)(xc)
+    plan = engine.Plan.from_modules(list(mods_g), 3, True)
+    xg = xs.clone().cuda().requires_grad_(True)
+    yg = engine.run_plan(plan, xg, False)
+    gy = torch.randn(yc.shape, generator=torch.Generator().manual_seed(5))
+    yc.backward(gy)
+    yg.backward(gy.cuda())
+    _close(yg, yc, 1.0, "stem + pool y")
+    _close(xg.grad, xc.grad, 3.0, "gradient wrt the image", frac=0.002)
+    _close(mods_g[0].weight.grad, mods_c[0].weight.grad, 3.0, "stem gw (un-fused pool backward)")
+    # without requires_grad on the input nothing of this runs (the training step's FLOP count skips the product)
+    xg2 = xs.clone().cuda()
+    engine.run_plan(plan, xg2, False).backward(gy.cuda())
+    assert xg2.grad is None

@@ -78,6 +78,26 @@ __device__ __forceinline__ f32x4 quad_max4(f32x4 v)
     return f32x4{a0, a1, a2, a3};
 }
 
+// minimum over the four lanes of a quad of four small unsigned keys (the first lane holding a maximum)
+__device__ __forceinline__ void quad_min4(unsigned (&k)[4])
+{
+    asm volatile("s_nop 1\n\t"
+                 "v_min_u32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                 "v_min_u32_dpp %1, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                 "v_min_u32_dpp %2, %2, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                 "v_min_u32_dpp %3, %3, %3 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                 "v_min_u32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+                 "v_min_u32_dpp %1, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+                 "v_min_u32_dpp %2, %2, %2 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+                 "v_min_u32_dpp %3, %3, %3 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf"
+                 : "+v"(k[0]), "+v"(k[1]), "+v"(k[2]), "+v"(k[3]));
+}
+
+__device__ __forceinline__ void store1(const void *base, unsigned voff, unsigned byte)
+{
+    asm volatile("global_store_byte %0, %1, %2\n\ts_nop 1" ::"v"(voff), "v"(byte), "s"(base) : "memory");
+}
+
 // two floats -> packed bf16 (round to nearest even, NaN stays NaN): ONE v_cvt_pk_bf16_f32 (casting the floats one by one costs a
 // conversion each plus a shift and an or)
 __device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi)
@@ -127,7 +147,8 @@ __device__ __forceinline__ void row_swap4(f32x4 &x, f32x4 &y)
     y = f32x4{y0, y1, y2, y3};
 }
 
-template <int NTILES, bool POOL, bool DGRAD>
+// CODES (with POOL): training's pooled map + 2-bit arg-max codes (pool2 = 3), in its own instantiation
+template <int NTILES, bool POOL, int DGRAD, bool CODES = false>
 __global__ void __launch_bounds__(512, 2) igemm_persist_kernel(const IgemmParams p)
 {
     using C = PersistCfg<NTILES>;
@@ -269,7 +290,7 @@ __global__ void __launch_bounds__(512, 2) igemm_persist_kernel(const IgemmParams
     unsigned px0_cur;
     tile_of(0, co0_cur, px0_cur);
     build_table(0, px0_cur);
-    const bool has_bias = p.epilogue == YOLO_EPI_BIAS || p.epilogue == YOLO_EPI_BIAS_LRELU;
+    const bool has_bias = p.epilogue == YOLO_EPI_BIAS || p.epilogue == YOLO_EPI_BIAS_LRELU || p.epilogue == YOLO_EPI_BIAS_ADD_LRELU;
     auto load_stash = [&](int co0) {
         const int lane = fresh_lane();
         const int ch = co0 + wco * 64 + lane;
@@ -354,8 +375,8 @@ __global__ void __launch_bounds__(512, 2) igemm_persist_kernel(const IgemmParams
         auto step_x = [&](auto zc, int nst, int rbuf, int lbuf, bf16x8(&ca)[MT], bf16x8(&cb)[NT0], bf16x8(&na)[MT], bf16x8(&nb)[NT0]) {
             // stores of the last epilogue: pooled NTG (one per column), else NTG per PAIR of channel tiles that exists
             if (nst == 0) wait_vmcnt<(D - 2) * LOADS>();
-            else if (POOL || nst <= 2) wait_vmcnt<(D - 2) * LOADS + NTG>();
-            else wait_vmcnt<(D - 2) * LOADS + 2 * NTG>();
+            else if (POOL ? !CODES : nst <= 2) wait_vmcnt<(D - 2) * LOADS + NTG>();
+            else wait_vmcnt<(D - 2) * LOADS + 2 * NTG>();       // (pooled map + code bytes, or two pairs of channel tiles)
             body(zc, rbuf, lbuf, ca, cb, na, nb);
         };
         // ---- epilogue of one tile, from the accumulator registers (lane: pixel column lane & 15, channels 4 * (lane >> 4) + r)
@@ -370,6 +391,51 @@ __global__ void __launch_bounds__(512, 2) igemm_persist_kernel(const IgemmParams
             const float slope = p.slope;
             if constexpr (POOL) {
                 const int e = lane & 3;
+                if constexpr (CODES) {
+                    // pool2 = 3: besides the pooled map, WHICH window element was the maximum (2 bits per channel; a lane's four channels
+                    // are one byte of the uint16 that holds eight) -- all the backward pass needs of the un-pooled activation.  As in the
+                    // LDS epilogue of igemm_pipe.hip the comparison runs on the activations AS THEY WOULD BE STORED (bias, LeakyReLU,
+                    // rounded to bf16) and the first maximum in window order (0,0), (0,1), (1,0), (1,1) = lanes 0 .. 3 of the quad wins.
+                    f32x4 bsa[MT];
+#pragma unroll
+                    for (int i = 0; i < MT; ++i) bsa[i] = *reinterpret_cast<const f32x4 *>(st + i * 16 + g4);
+                    const unsigned chb = (unsigned)((co0 + wco * 64 + e * 16 + g4) * 2);
+                    const unsigned cdb = (unsigned)((co0 + wco * 64 + e * 16) >> 2) + (unsigned)(lane >> 4);       // byte of this lane's code
+                    const bool lrelu = p.epilogue == YOLO_EPI_BIAS_LRELU;
+#pragma unroll
+                    for (int j = 0; j < NTG; ++j) {
+                        const unsigned obp = tb_[(px_lo + j * 16 + (lane & 15)) * 4 + 1];
+                        f32x4 sel = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+                        unsigned code = 0;
+#pragma unroll
+                        for (int i = 0; i < MT; ++i) {
+                            f32x4 t;
+#pragma unroll
+                            for (int r = 0; r < 4; r += 2) {
+                                float t0 = acc[i][j][r] + bsa[i][r], t1 = acc[i][j][r + 1] + bsa[i][r + 1];
+                                t0 = (lrelu && t0 < 0.0f) ? t0 * slope : t0;
+                                t1 = (lrelu && t1 < 0.0f) ? t1 * slope : t1;
+                                const unsigned pk = pack_bf16x2(t0, t1);
+                                t[r] = __uint_as_float(pk << 16);
+                                t[r + 1] = __uint_as_float(pk & 0xffff0000u);
+                            }
+                            const f32x4 m = quad_max4(t);
+                            unsigned key[4];
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) key[r] = (t[r] == m[r]) ? (unsigned)e : 4u;
+                            quad_min4(key);
+                            const unsigned c4 = key[0] | (key[1] << 2) | (key[2] << 4) | (key[3] << 6);
+                            code = (e == i) ? c4 : code;
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) sel[r] = (e == i) ? m[r] : sel[r];
+                        }
+                        const unsigned lo = pack_bf16x2(sel[0], sel[1]), hi = pack_bf16x2(sel[2], sel[3]);      // (exact: already bf16 values)
+                        if (e < nvi) {
+                            store8<0>(p.out, obp + chb, lo, hi);
+                            store1(p.aux, (obp >> 3) + cdb, code);
+                        }
+                    }
+                } else {
                 // bias of the channel tile this lane stores (tile e of the wave's four)
                 const f32x4 bs = *reinterpret_cast<const f32x4 *>(st + e * 16 + g4);
                 const unsigned chb = (unsigned)((co0 + wco * 64 + e * 16 + g4) * 2);
@@ -391,6 +457,7 @@ __global__ void __launch_bounds__(512, 2) igemm_persist_kernel(const IgemmParams
                     }
                     const unsigned lo = pack_bf16x2(v[0], v[1]), hi = pack_bf16x2(v[2], v[3]);
                     if (e < nvi) store8<0>(p.out, ob, lo, hi);        // (issued once per column by every wave with nvi > 0)
+                }
                 }
             } else {
                 // Two channel tiles (i0, i0 + 1) at a time: after swapping rows 1 / 3 of tile i0's registers with rows 0 / 2 of tile
@@ -423,12 +490,20 @@ __global__ void __launch_bounds__(512, 2) igemm_persist_kernel(const IgemmParams
                         f32x4 x = acc[2 * pr][j], y = acc[2 * pr + 1][j];
                         row_swap4(x, y);
                         float v[8] = {x[0], x[1], x[2], x[3], y[0], y[1], y[2], y[3]};
-                        if constexpr (DGRAD) {
+                        if constexpr (DGRAD == 1) {
                             const unsigned yy[4] = {ax[pr].x, ax[pr].y, ax[pr].z, ax[pr].w};
 #pragma unroll
                             for (int k = 0; k < 8; ++k) {
                                 const float a = __uint_as_float((k & 1) ? (yy[k >> 1] & 0xffff0000u) : (yy[k >> 1] << 16));
                                 v[k] = a > 0.0f ? v[k] : v[k] * slope;
+                            }
+                        } else if constexpr (DGRAD == 2) {
+                            const unsigned yy[4] = {ax[pr].x, ax[pr].y, ax[pr].z, ax[pr].w};
+#pragma unroll
+                            for (int k = 0; k < 8; ++k) {
+                                float t = v[k] + bs[pr][k >> 2][k & 3];
+                                t += __uint_as_float((k & 1) ? (yy[k >> 1] & 0xffff0000u) : (yy[k >> 1] << 16));
+                                v[k] = t > 0.0f ? t : t * slope;
                             }
                         } else {
 #pragma unroll
@@ -529,7 +604,7 @@ static void magic_u31(unsigned d, unsigned &magic, unsigned &shift)
     shift = l - 1;
 }
 
-template <int NTILES, bool POOL, bool DGRAD>
+template <int NTILES, bool POOL, int DGRAD, bool CODES = false>
 static int persist_launch(const IgemmParams &p, hipStream_t s)
 {
     using C = PersistCfg<NTILES>;
@@ -538,7 +613,7 @@ static int persist_launch(const IgemmParams &p, hipStream_t s)
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
     if (!attr_done[dev]) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&igemm_persist_kernel<NTILES, POOL, DGRAD>), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&igemm_persist_kernel<NTILES, POOL, DGRAD, CODES>), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
         if (e != hipSuccess) return fail((int)e, "yolo_igemm: hipFuncSetAttribute(%d B LDS): %s", C::LDS_BYTES, hipGetErrorString(e));
         int n = 0;
         if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
@@ -557,7 +632,7 @@ static int persist_launch(const IgemmParams &p, hipStream_t s)
     magic_u31((unsigned)p.Wo / 2, q.div_hw2_magic, q.div_hw2_shift);
     const long tiles = (long)q.n_co_tiles * q.n_px_tiles;
     const int G = (int)std::min<long>(tiles, cus[dev]);
-    hipLaunchKernelGGL((igemm_persist_kernel<NTILES, POOL, DGRAD>), dim3(G), dim3(C::NTHR), C::LDS_BYTES, s, q);
+    hipLaunchKernelGGL((igemm_persist_kernel<NTILES, POOL, DGRAD, CODES>), dim3(G), dim3(C::NTHR), C::LDS_BYTES, s, q);
     return check_launch("yolo_igemm (persistent)");
 }
 
@@ -568,8 +643,7 @@ int igemm_persist_launch(const IgemmParams &p, int hint, int splits, hipStream_t
     if (p.tap_len % 32) return fail(YOLO_E_UNSUPPORTED, "yolo_igemm: tile_hint %d needs tap_len %% 32 == 0", hint);
     const long nk = p.Ktot / 32;
     if (nk % 2 || nk < 6) return fail(YOLO_E_UNSUPPORTED, "yolo_igemm: tile_hint %d needs an even number (>= 6) of 32-deep K steps", hint);
-    if (p.epilogue != YOLO_EPI_NONE && p.epilogue != YOLO_EPI_BIAS && p.epilogue != YOLO_EPI_BIAS_LRELU && p.epilogue != YOLO_EPI_MUL_DLRELU)
-        return fail(YOLO_E_UNSUPPORTED, "yolo_igemm: tile_hint %d has no epilogue %d", hint, p.epilogue);
+    if (p.epilogue < YOLO_EPI_NONE || p.epilogue > YOLO_EPI_BIAS_ADD_LRELU) return fail(YOLO_E_UNSUPPORTED, "yolo_igemm: tile_hint %d has no epilogue %d", hint, p.epilogue);
     if (!(p.slope >= 0.0f && p.slope <= 1.0f)) return fail(YOLO_E_UNSUPPORTED, "yolo_igemm: tile_hint %d needs 0 <= slope <= 1", hint);
     if (p.Cout > 256 && p.Cout % 256) return fail(YOLO_E_UNSUPPORTED, "yolo_igemm: tile_hint %d needs Cout <= 256 or Cout %% 256 == 0", hint);
     if (p.Cout % 16) return fail(YOLO_E_UNSUPPORTED, "yolo_igemm: tile_hint %d needs Cout %% 16 == 0", hint);
@@ -582,18 +656,20 @@ int igemm_persist_launch(const IgemmParams &p, int hint, int splits, hipStream_t
         return fail(YOLO_E_UNSUPPORTED, "yolo_igemm: tile_hint %d addresses operands below 4 GB", hint);
     if ((p.out_off | p.out_px_stride | p.out_row_stride) & 3 || (p.out_img_stride & 3))
         return fail(YOLO_E_UNSUPPORTED, "yolo_igemm: tile_hint %d stores 8-byte pieces: output strides in multiples of 4 elements", hint);
-    if (p.epilogue == YOLO_EPI_MUL_DLRELU && ((p.aux_off | p.aux_px_stride | p.aux_row_stride) & 3 || (p.aux_img_stride & 3)))
+    if ((p.epilogue == YOLO_EPI_MUL_DLRELU || p.epilogue == YOLO_EPI_BIAS_ADD_LRELU) && ((p.aux_off | p.aux_px_stride | p.aux_row_stride) & 3 || (p.aux_img_stride & 3)))
         return fail(YOLO_E_UNSUPPORTED, "yolo_igemm: tile_hint %d reads aux in 8-byte pieces", hint);
     if (p.pool) {
-        if (hint != 21 || p.pool != 1 || !(p.Wo == 112 || p.Wo == 56 || p.Wo == 28) || (p.HoWo / p.Wo) % 2 || p.M % 224
+        if (hint != 21 || (p.pool != 1 && p.pool != 3) || !(p.Wo == 112 || p.Wo == 56 || p.Wo == 28) || (p.HoWo / p.Wo) % 2 || p.M % 224
             || (p.epilogue != YOLO_EPI_BIAS && p.epilogue != YOLO_EPI_BIAS_LRELU))
-            return fail(YOLO_E_UNSUPPORTED, "yolo_igemm: the pooled epilogue of tile_hint 21 needs pool2 = 1, rows of 112, 56 or 28 pixels and whole 224-pixel tiles");
-        return persist_launch<14, true, false>(p, s);
+            return fail(YOLO_E_UNSUPPORTED, "yolo_igemm: the pooled epilogue of tile_hint 21 needs pool2 = 1 or 3, rows of 112, 56 or 28 pixels and whole 224-pixel tiles");
+        if (p.pool == 3 && ((p.out_off | p.out_px_stride | p.out_row_stride) & 7 || (p.out_img_stride & 7) || (p.Cout & 7)))
+            return fail(YOLO_E_UNSUPPORTED, "yolo_igemm: pool2 = 3 needs Cout and the output strides in multiples of 8");
+        return p.pool == 3 ? persist_launch<14, true, 0, true>(p, s) : persist_launch<14, true, 0>(p, s);
     }
-    const bool dg = p.epilogue == YOLO_EPI_MUL_DLRELU;
+    const int dg = p.epilogue == YOLO_EPI_MUL_DLRELU ? 1 : (p.epilogue == YOLO_EPI_BIAS_ADD_LRELU ? 2 : 0);
     switch (hint) {
-    case 20: return dg ? persist_launch<13, false, true>(p, s) : persist_launch<13, false, false>(p, s);
-    case 21: return dg ? persist_launch<14, false, true>(p, s) : persist_launch<14, false, false>(p, s);
+    case 20: return dg == 1 ? persist_launch<13, false, 1>(p, s) : (dg == 2 ? persist_launch<13, false, 2>(p, s) : persist_launch<13, false, 0>(p, s));
+    case 21: return dg == 1 ? persist_launch<14, false, 1>(p, s) : (dg == 2 ? persist_launch<14, false, 2>(p, s) : persist_launch<14, false, 0>(p, s));
     }
     return fail(YOLO_E_ARG, "yolo_igemm: tile_hint %d is not a persistent configuration", hint);
 }

@@ -25,7 +25,7 @@ import torch
 import torch.nn as nn
 
 from . import _hip
-from ._hip import (EPI_BIAS, EPI_BIAS_LRELU, EPI_MUL_DLRELU, EPI_NONE, ConvPackItem, ConvUnpackItem, IgemmDesc, PoolDesc, WgradDesc, check, lib, ptr,
+from ._hip import (EPI_BIAS, EPI_BIAS_ADD_LRELU, EPI_BIAS_LRELU, EPI_MUL_DLRELU, EPI_NONE, ConvPackItem, ConvUnpackItem, IgemmDesc, PoolDesc, WgradDesc, check, lib, ptr,
                    stream)
 
 
@@ -58,6 +58,7 @@ STEM_F32_INPUT = True  # inference: the stem kernel reads the NCHW fp32 input it
 FLATTEN_FREE = True  # inference: conv -> nn.Flatten -> Linear without the flatten pass (dense NHWC conv output + K-permuted weight panels)
 POOL_CODES = True  # training: a fused conv + pool stores the pooled map and 2-bit arg-max codes, not the un-pooled activation
 FUSE_POOL = True   # inference: fold MaxPool2d(2,2) into the preceding conv's epilogue where the geometry allows
+PERSIST = True     # plans with the persistent kernels (tile_hint 20 / 21) run them (False: the pipelined kernels 15 / 16 instead -- for A/B runs)
 
 
 def _igemm(L_, d, inp, w, bias, aux, out, st, what):
@@ -238,7 +239,7 @@ def _persist_ok(d: IgemmDesc) -> bool:
     registers) take the problem: an even number >= 6 of 32-deep K steps, whole 256-channel tiles (or one ragged tile), bf16 output"""
     nk = d.KH * d.KW * d.tap_len // 32
     return (d.tap_len % 32 == 0 and nk % 2 == 0 and nk >= 6 and not d.bn_stats and not d.w_blocked and not d.out_fp32 and d.split_k <= 1
-            and (d.Cout <= 256 or d.Cout % 256 == 0) and d.Cout % 16 == 0 and d.epilogue in (EPI_NONE, EPI_BIAS, EPI_BIAS_LRELU, EPI_MUL_DLRELU))
+            and (d.Cout <= 256 or d.Cout % 256 == 0) and d.Cout % 16 == 0 and d.epilogue in (EPI_NONE, EPI_BIAS, EPI_BIAS_LRELU, EPI_MUL_DLRELU, EPI_BIAS_ADD_LRELU))
 
 
 def _pipe_pool_ok(d: IgemmDesc) -> bool:
@@ -251,12 +252,19 @@ def _default_plan(d: IgemmDesc):
     rounds over the chip's workgroup slots x relative tile time (deterministic, no timing)."""
     M = d.N * d.Ho * d.Wo
     if d.pool2:
-        # the library's own pooled epilogue tiles 8 x 16 pixel patches; other maps go through the 224-pixel pipelined tiles
+        # the library's own pooled epilogue tiles 8 x 16 pixel patches; other maps go through the 224-pixel pipelined / persistent tiles
         if d.Ho % 8 == 0 and d.Wo % 16 == 0 and not (_pipe_pool_ok(d) and d.Cout >= 192):
             return (0, 0)
+        if _persist_ok(d) and d.pool2 in (1, 3) and M % 224 == 0 and d.Cout > 128:
+            return ("tile", 21, 1, 0)
         return ("tile", 16 if d.Cout > 128 else 18, 1, 0)
     if M < 2048:
         return (0, 0)
+    if _persist_ok(d) and d.Cout >= 192 and M * ((d.Cout + 255) // 256) >= 96 * 208:
+        # the persistent kernel (one software pipeline over a workgroup's tiles, epilogue out of the registers) won 42 of the 90 problems
+        # measured at batch 64, every one with >= 192 output channels and enough tiles for half the chip; 196-pixel tiles where they
+        # divide the pixels (this network's maps are 49 * 4^k pixels)
+        return ("tile", 20, 1, 196 if M % 196 == 0 else 208)
     best, best_t = (0, 0), None
     for hint, (slots, cost) in _TILE_COST.items():
         tco, tpx = _TILE[hint]
@@ -277,9 +285,10 @@ def _run_plan_igemm(L_, d: IgemmDesc, plan, inp, w, bias, aux, out, st, what):
     if d.bn_stats and (plan[0] in ("splitk", "slabs") or (isinstance(plan[0], int) and len(plan) == 4)):
         # a launch that also accumulates BatchNorm statistics must be one plain launch: keep the plan's main configuration
         plan = (plan[1], 1) if plan[0] in ("splitk", "slabs") else (plan[0], plan[1])
-    if plan[0] == "tile" and plan[1] in (20, 21) and (d.pool2 in (2, 3) or not _persist_ok(d)):
-        # the persistent kernels pool for inference only (pool2 = 1): training's pooled map + un-pooled activation / arg-max codes, and
-        # anything else they do not take (a plan measured for pool2 = 1 also serves pool2 = 3, see _tune_key), run the pipelined kernels
+    if plan[0] == "tile" and plan[1] in (20, 21) and (d.pool2 == 2 or not PERSIST or not _persist_ok(d)):
+        # the persistent kernels pool with pool2 = 1 (inference) and 3 (training: pooled map + arg-max codes; a plan measured for
+        # pool2 = 1 also serves pool2 = 3, see _tune_key); pooled map + un-pooled activation (pool2 = 2), and anything else they do not
+        # take, run the pipelined kernels
         plan = ("tile", 16 if (d.pool2 or plan[1] == 21) else 15, plan[2], 0 if d.pool2 else plan[3]) + tuple(plan[4:])
     if d.bn_stats:      # the pipelined kernels (15 .. 18) have no statistics epilogue: the staggered 256 x 208 loop takes their place
         if plan[0] == "tile" and plan[1] in (15, 16, 17, 18):
@@ -393,7 +402,7 @@ def _tune(L_, d: IgemmDesc, inp, w, bias, aux, out, st, what):
     elif _pipe_pool_ok(d):
         consider(("tile", 16, 1, 0))                    # MaxPool2d(2,2) fused into the pipelined kernels' epilogue
         consider(("tile", 18, 1, 0))
-        if _persist_ok(d) and d.pool2 == 1 and M % 224 == 0:
+        if _persist_ok(d) and d.pool2 in (1, 3) and M % 224 == 0:
             consider(("tile", 21, 1, 0))                # ... and into the persistent kernel's register epilogue (quad-permute max)
     # tail plans: the two fastest large-tile configurations, cut where their tiles stop filling whole rounds of
     # 256 (one workgroup per CU) or 512 slots, remainder with a small tile
@@ -1299,7 +1308,8 @@ class Plan:
                 Lc = self.layers[lc]
                 assert Lc.kind == "conv" and Lc.lrelu, "MaxPool2d is expected right after conv+LeakyReLU"
                 yfull = ws["acts"][lc]
-                if lc == 0 and Lc.first and STEM_POOL_BWD_FUSED and Lc.Cout == 64 and Lc.Hout % 8 == 0 and Lc.Wout % 16 == 0 and g_act.halo == 1:
+                if (lc == 0 and Lc.first and STEM_POOL_BWD_FUSED and Lc.Cout == 64 and Lc.Hout % 8 == 0 and Lc.Wout % 16 == 0 and g_act.halo == 1
+                        and not need_gx):      # (a gradient wrt the input image needs the stem's output gradient as a tensor)
                     # the stem's weight-gradient kernel rebuilds this pool's (+ LeakyReLU's) backward per tile from the
                     # activation and the pooled gradient: the 224x224x64 gradient buffer is never written or read
                     stem_dpool = g_act
@@ -1383,9 +1393,7 @@ class Plan:
                             self.on_stream_wait(main_t.cuda_stream, side_t.cuda_stream)
                     gx = None
                     if need_gx:
-                        if L.first:
-                            raise NotImplementedError("gradient wrt the input image is not provided for the 7x7 stem")
-                        gx = self._dgrad_to_input(li, g, N, dev, st)
+                        gx = self._stem_dgrad(li, g, N, dev, st) if L.first else self._dgrad_to_input(li, g, N, dev, st)
                     if self.debug_keep:
                         self.last = (ws, fc_saved)
                     else:
@@ -1476,6 +1484,35 @@ class Plan:
             g.interior().copy_(gi)
         else:
             g.interior()[:, 0::2, 0::2, :][:, : gi.shape[1], : gi.shape[2], :].copy_(gi)
+
+    def _stem_dgrad(self, li, g: Act, N, dev, st):
+        """gradient wrt the input IMAGE through the 7x7 / stride-2 / pad-3 stem (the reference back-propagates to x in
+        tests/test_backbone.py:187-196; training never asks for it, so the step's FLOP count skips this product).  By the parity
+        (py, px) of the image pixel (y, x) = (2a + py, 2b + px) only the taps ky = py + 5 - 2 ty (ty = 0 .. 2 + py; likewise kx) meet an
+        output pixel, (a + ty - 1, b + tx - 1): four stride-1 correlations over the stem's output gradient g with 3x3, 3x4, 4x3 and 4x4
+        taps of 64 channels, each writing its parity class of the image (doubled output strides) -- the scheme of the stride-2 3x3
+        layers' data gradient.  The three image channels ride in an 8-channel fp32 NHWC scratch; rows / columns a + 2 past the map fall
+        on the zero halo of the next row / image (or the guard band)."""
+        L = self.layers[li]
+        assert L.first and L.K == 7 and L.stride == 2 and L.pad == 3 and g.halo == 1 and g.C == L.Cout and L.Cout % 64 == 0
+        H, W = 2 * L.Hout, 2 * L.Wout
+        w = L.weight.detach().float()                                   # [Cout][3][7][7]
+        buf = torch.empty((N, H, W, 8), dtype=torch.float32, device=dev)
+        L_ = lib()
+        for py in (0, 1):
+            for px in (0, 1):
+                kys = [py + 5 - 2 * t for t in range(3 + py)]
+                kxs = [px + 5 - 2 * t for t in range(3 + px)]
+                panel = torch.zeros((8, len(kys), len(kxs), L.Cout), dtype=torch.bfloat16, device=dev)
+                panel[:3] = w[:, :, kys][:, :, :, kxs].permute(1, 2, 3, 0).to(torch.bfloat16)      # [c][ty][tx][co]
+                d = IgemmDesc()
+                d.N, d.Ho, d.Wo = N, L.Hout, L.Wout
+                d.in_img_stride, d.in_row_stride, d.in_px_stride, d.in_off = g.img_stride, g.row_stride, g.px_stride, g.interior_off(1)
+                d.stride, d.KH, d.KW, d.tap_len, d.Cout = 1, len(kys), len(kxs), L.Cout, 8
+                d.out_img_stride, d.out_row_stride, d.out_px_stride, d.out_off = H * W * 8, 2 * W * 8, 16, (py * W + px) * 8
+                d.epilogue, d.slope, d.out_fp32, d.split_k, d.tile_hint = EPI_NONE, self.SLOPE, 1, 1, 4      # 64 x 128 tiles: 8 "channels"
+                _igemm(L_, d, g.p, ptr(panel), None, None, ptr(buf), st, f"stem dgrad class {py}{px}")
+        return buf[..., :3].permute(0, 3, 1, 2).contiguous()
 
     def _dgrad_to_input(self, li, g: Act, N, dev, st):
         """data gradient of the first conv of a plan whose input is a feature map (DetectionHead)."""
