@@ -61,25 +61,35 @@ def timed_steps(fn, steps, warmup, world):
     return dt
 
 
-def kernel_rooflines(fn, reps=2):
-    """run `fn` reps times with every MFMA launch bracketed by events on the launch stream (engine.TIMERS) and return
-    {kernel kind: roofline block} for the MFMA kernels: achieved = algorithmic FLOPs of the launches / their summed durations"""
+def kernel_rooflines(fn, reps=2, alone=True):
+    """run `fn` reps times with every MFMA launch bracketed by events on ITS launch stream (engine.TIMERS) and return
+    {kernel kind: roofline block} for the MFMA kernels: achieved = algorithmic FLOPs of the launches / their summed durations.
+    ``alone``: the backward pass on ONE stream, so that every launch has the chip to itself (the step itself runs the weight gradients
+    on a second stream beside the data-gradient chain; with alone=False the events sit on both streams and the durations are those of
+    the schedule that actually runs -- overlapping launches share the CUs, so a launch reads longer and the sums exceed the step)."""
     from yolo import engine
+    keep = engine.WGRAD_STREAM
+    if alone:
+        engine.WGRAD_STREAM = False
     engine.TIMERS = []
     n0 = engine.IGEMM_LAUNCHES
-    for _ in range(reps):
-        fn()
-    torch.cuda.synchronize()
+    try:
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize()
+    finally:
+        timers, engine.TIMERS = engine.TIMERS, None
+        engine.WGRAD_STREAM = keep
     launches = (engine.IGEMM_LAUNCHES - n0) // reps
     agg = {}
-    for tag, kern, flops, e0, e1 in engine.TIMERS:
+    for tag, kern, flops, e0, e1 in timers:
         d = agg.setdefault(kern, [0.0, 0.0, 0])
         d[0] += e0.elapsed_time(e1) / reps
         d[1] += flops / reps
         d[2] += 1
-    engine.TIMERS = None
-    names = {"igemm": "igemm_kernel / igemm_pipe_kernel / igemm_stream_kernel (implicit GEMM: conv / Linear forward and data gradient)",
-             "wgrad": "wgrad_kernel / wgrad_pipe_kernel (weight gradient, ds_read_b64_tr_b16 operands; each launch timed alone -- the step itself runs them on a second stream beside the data gradients)", "stem": "stem_fwd_kernel (7x7/s2 stem)"}
+    how = "each launch timed alone -- one stream" if alone else "as scheduled: weight gradients on the second stream beside the data gradients, events on both streams"
+    names = {"igemm": "igemm_persist_kernel / igemm_pipe_kernel / igemm_kernel / igemm_stream_kernel (implicit GEMM: conv / Linear forward and data gradient; " + how + ")",
+             "wgrad": "wgrad_kernel / wgrad_pipe_kernel (weight gradient, ds_read_b64_tr_b16 operands; " + how + ")", "stem": "stem_fwd_kernel (7x7/s2 stem)"}
     out = {}
     for kern, (ms, fl, n) in agg.items():
         if fl <= 0 or kern not in names:
@@ -91,6 +101,14 @@ def kernel_rooflines(fn, reps=2):
     if "igemm" in out:
         out["igemm"]["launches_per_step"] = launches
     return out
+
+
+def _profile_traffic(suffix):
+    """HBM bytes per launch from the newest committed profiles/*<suffix> (PMC passes cannot run inside a bench run)"""
+    names = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith(suffix))
+    if not names:
+        return None, "-"
+    return round(json.load(open(os.path.join(ROOT, "profiles", names[-1])))["hbm_bytes_per_launch"]), names[-1]
 
 
 def _launch_ranks(n: int) -> None:
@@ -274,14 +292,10 @@ def main():
         # HBM bytes per launch from PMC counters: measured by tools/collect_traffic.sh (two separate
         # rocprofv3 --pmc passes of this very command) and committed under profiles/ -- a bench run
         # cannot profile itself
-        traffic = None
-        tnames = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("igemm_traffic.json"))
-        tpath = os.path.join(ROOT, "profiles", tnames[-1]) if tnames else ""
-        if tnames:
-            traffic = round(json.load(open(tpath))["hbm_bytes_per_launch"])
-        roof = {"kernel": "igemm_kernel / igemm_pipe_kernel / igemm_stream_kernel (implicit-GEMM conv/FC, v_mfma_f32_16x16x32_bf16)", "bound": "mfma",
+        traffic, tname = _profile_traffic("igemm_traffic.json")
+        roof = {"kernel": "igemm_persist_kernel / igemm_pipe_kernel / igemm_kernel / igemm_stream_kernel (implicit-GEMM conv/FC, v_mfma_f32_16x16x32_bf16)", "bound": "mfma",
                 "achieved": round(ach, 2), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4),
-                "traffic": traffic, "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE + WRITE_SIZE with the guide's gfx950 corrections, profiles/" + (os.path.basename(tpath) if tnames else "-") + ")",
+                "traffic": traffic, "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE + WRITE_SIZE with the guide's gfx950 corrections, profiles/" + tname + ")",
                 "launches_per_step": n_launch, "avg_launch_ms": round(ig_ms / n_launch, 4),
                 "flops_per_launch": ig_fl / n_launch, "flops_per_step": ig_fl, "kernel_ms_per_step": round(ig_ms, 3)}
         if a.layers:
@@ -297,9 +311,10 @@ def main():
         crit = YOLOLoss()
         from yolo.optim import Adam
         opt = Adam(model.parameters(), lr=1e-4, weight_decay=5e-4, max_grad_norm=10.0)  # clip_grad_norm_(10) + Adam fused
-        # Adam also refreshes the bf16 operands of the Linear layers, and updates them as a background pass on 64 CUs of a second stream
-        # beside the next forward's conv stack (the forward waits for it in front of its first Linear layer)
-        opt.attach_plan(model.hip_plan(), overlap=True)
+        # Adam also refreshes the bf16 operands of the Linear layers in the same pass.  (Round 2 ran their update as a background pass on 64
+        # CUs beside the next forward's conv stack; the persistent conv kernels of round 3 want all 256 CUs -- a workgroup per CU walks
+        # the tiles -- and lose more to the 64 held CUs than the overlap hides: 11.24 ms per step without it, 11.53 with, same process.)
+        opt.attach_plan(model.hip_plan(), overlap=False)
         # data parallel: gradient arena + all-reduce overlapped with the backward pass (FC1's 822 MB first)
         ar = make_grad_reducer(model, dev) if (use_dist and world > 1) else None      # the reducer the shipped training loop uses (nothing to reduce in a world of one)
 
@@ -359,17 +374,23 @@ def main():
                 ms = e0.elapsed_time(e1)
                 print(f"train {tag:16s} {kern:14s} {ms:8.3f} ms {flops / max(ms, 1e-9) / 1e9:9.1f} TFLOP/s", file=sys.stderr)
             engine.TIMERS = None
-        def step_alone():                   # for the per-launch rooflines: no background optimizer pass of the previous step beside the kernels
+        def step_alone():                   # for the per-launch rooflines: every step behind a full synchronisation
             opt.synchronize()
             torch.cuda.synchronize()
             step()
 
         troof = kernel_rooflines(step_alone)      # on every rank: the step holds a collective when N > 1
+        sroof = kernel_rooflines(step, alone=False)
+        wtraffic, wname = _profile_traffic("wgrad_traffic.json")
+        if troof.get("wgrad") is not None:
+            troof["wgrad"]["traffic"] = wtraffic
+            troof["wgrad"]["traffic_unit"] = "HBM bytes per launch (PMC FETCH_SIZE + WRITE_SIZE with the guide's gfx950 corrections, profiles/" + wname + ")"
         train = {"value": round(world * B * ksteps / dt_t, 1), "unit": "images/s", "ms_per_step": round(1e3 * dt_t / ksteps, 3),
                  "steps": ksteps, "global_batch": world * B,
                  "step_tflops": round(120.8e9 * world * B / (dt_t / ksteps) / 1e12, 1),
                  "roofline": troof.get("wgrad"), "roofline_igemm": troof.get("igemm"),
-                 "includes": "zero_grad, forward, YOLOLoss fwd+bwd (HIP), backward (HIP), " + ("RCCL grad all-reduce overlapped with backward, " if ar is not None else "") + "clip_grad_norm_(10), Adam(lr 1e-4, wd 5e-4; the Linear layers' update as a background pass beside the next forward)",
+                 "roofline_as_scheduled": {"wgrad": sroof.get("wgrad"), "igemm": sroof.get("igemm")},
+                 "includes": "zero_grad, forward, YOLOLoss fwd+bwd (HIP), backward (HIP), " + ("RCCL grad all-reduce overlapped with backward, " if ar is not None else "") + "clip_grad_norm_(10), Adam(lr 1e-4, wd 5e-4) fused in one multi-tensor pass",
                  "flops_per_image": 120.8e9, "first_layer_dgrad": "skipped (input needs no gradient)"}
         if dp is not None:
             train.update(dp)

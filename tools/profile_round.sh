@@ -4,6 +4,8 @@
 #      <tag>_roofline_pass_from_trace.txt (kernel-trace durations of the roofline pass vs bench.py's own HIP events)
 #   2. HBM traffic of the forward's igemm launches (two separate --pmc passes) -> profiles/<tag>_igemm_traffic.json
 #   3. SQ counters (MFMA busy, LDS conflicts, issue stalls; two --pmc passes)   -> profiles/<tag>_igemm_sq_pmc.txt
+#   4. the same for the weight-gradient kernels over three training steps       -> profiles/<tag>_wgrad_traffic.json, <tag>_wgrad_pmc.txt
+#   5. kernel stats of the training step alone                                  -> profiles/<tag>_train_step_kernels.txt
 # Counter passes never run together with tracing (MI355X_MICROARCH.md, rocprofv3 PMC).
 set -e
 TAG=${1:-r2_v1}
@@ -21,4 +23,10 @@ cp "$OUT/traffic/igemm_traffic.json" profiles/${TAG}_igemm_traffic.json
 cat profiles/${TAG}_igemm_traffic.json
 bash tools/pmc_igemm.sh "$OUT/pmc" > profiles/${TAG}_igemm_sq_pmc.txt
 tail -20 profiles/${TAG}_igemm_sq_pmc.txt
-python3 bench.py --no-cpu > profiles/${TAG}_bench_unprofiled.json 2> /dev/null
+bash tools/collect_wgrad_traffic.sh "$OUT/wgrad" > /dev/null
+cp "$OUT/wgrad/wgrad_traffic.json" profiles/${TAG}_wgrad_traffic.json
+cp "$OUT/wgrad/wgrad_pmc.txt" profiles/${TAG}_wgrad_pmc.txt
+cat profiles/${TAG}_wgrad_traffic.json
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT" -o train -- python3 tools/train_steps.py 10 > "$OUT/train.log" 2>&1
+python3 tools/kstats.py "$OUT"/train_kernel_stats.csv 40 > profiles/${TAG}_train_step_kernels.txt
+python3 bench.py > profiles/${TAG}_bench_unprofiled.json 2> /dev/null

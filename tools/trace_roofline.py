@@ -9,7 +9,7 @@ marks = [i for i, r in enumerate(rows) if r["Kernel_Name"].startswith("yolo::sum
 assert len(marks) >= 2, "marker launches not found"
 seg = rows[marks[0] + 1: marks[1]]
 def _ig(name):
-    return "igemm_kernel" in name or "igemm_pipe_kernel" in name or "igemm_stream_kernel" in name
+    return "igemm_kernel" in name or "igemm_pipe_kernel" in name or "igemm_stream_kernel" in name or "igemm_persist_kernel" in name
 ig = [r for r in seg if _ig(r["Kernel_Name"])]
 dur = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6 for r in ig]
 other = sum((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6 for r in seg if not _ig(r["Kernel_Name"]))

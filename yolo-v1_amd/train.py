@@ -79,7 +79,9 @@ def main():
         from yolo.optim import Adam          # fused clip(10) + Adam on the HIP kernels
         optimizer = Adam(params, lr=a.lr, weight_decay=a.weight_decay, max_grad_norm=10.0)
         if model._fusable():
-            optimizer.attach_plan(model.hip_plan(), overlap=True)      # Linear layers' update as a background pass beside the next forward
+            # (overlap=True -- the Linear layers' update as a background pass beside the next forward -- is available, but loses against
+            # the persistent conv kernels, which want every CU: 11.24 vs 11.53 ms per step at batch 64)
+            optimizer.attach_plan(model.hip_plan())
         elif hasattr(model.head, "hip_plan"):          # DetectionHead on a ResNet trunk: its Linear layers' bf16 operands
             optimizer.attach_plan(model.head.hip_plan())
     else:

@@ -1,0 +1,45 @@
+"""Switches and measurement hooks of the engine (round 3: one object instead of module-level globals of engine.py).
+
+``CONFIG`` is the process-wide default; an executor (``executor.Plan``, ``resnet_executor.ResNetPlan``) reads ``plan.cfg`` if it was given its own
+``EngineConfig`` (``plan.cfg = dataclasses.replace(CONFIG, WGRAD_STREAM=False)``) and ``CONFIG`` otherwise, so a measurement can pin the schedule of ONE
+plan without touching the others.  The measurement hooks (``TIMERS``) never change the schedule: round 2's ``TIMERS is not None`` silently
+switched the second stream of the backward pass off; now the per-launch events are recorded on whichever stream a launch runs on, and whoever wants
+every launch alone on the chip says so (``WGRAD_STREAM = False``, bench.py's "each launch alone" figures).  ``yolo.engine`` forwards attribute reads and
+writes of these names to ``CONFIG`` (``engine.FUSE_POOL = False`` keeps working)."""
+
+from __future__ import annotations
+
+from dataclasses import dataclass, fields
+
+
+@dataclass
+class EngineConfig:
+    # ---- measurement hooks (do not change what runs)
+    TIMERS: list | None = None       # a list: every MFMA / pool launch is bracketed by events ON ITS LAUNCH STREAM, (tag, kernel, flops, e0, e1) appended
+    IGEMM_LAUNCHES: int = 0          # yolo_igemm launches so far (bench.py: launches per step of the dominant kernel)
+    TUNE_LOG: list | None = None     # tools/tune_plans.py: (key, winner, six fastest candidates with their times)
+    # ---- launch plans
+    AUTOTUNE: bool = False           # tools/tune_plans.py only: time the candidate plans of a problem without a table entry
+    TILE_HINT: int = 0               # tests / tuning: force a tile configuration of yolo_igemm (0 = plan table; yolo_igemm_desc.tile_hint)
+    TILE_PX: int = 0                 # with TILE_HINT: yolo_igemm_desc.tile_px of the forced configuration
+    PERSIST: bool = True             # plans with the persistent kernels (tile_hint 20 / 21) run them (False: the pipelined kernels 15 / 16 -- A/B runs)
+    # ---- what is fused
+    BN_STATS_IN_CONV: bool = True    # ResNet trunk in batch-statistics mode: BatchNorm's sums come out of the conv's epilogue (yolo_igemm_desc.bn_stats)
+    STEM_KERNEL: bool = True         # 7x7/s2 stem through yolo_conv_stem7_fwd (False: the generic row-segment implicit GEMM; tests compare)
+    STEM_POOL_BWD_FUSED: bool = True # backward of the pool + LeakyReLU behind the stem inside yolo_wgrad_stem7_pooled (False: separate pass)
+    STRIDE2_CLASSES: bool = True     # data gradient of a stride-2 3x3 conv as four parity-class convs over the non-zero gradient slots
+    STEM_F32_INPUT: bool = True      # inference: the stem kernel reads the NCHW fp32 input itself (no separate layout pass)
+    FLATTEN_FREE: bool = True        # inference: conv -> nn.Flatten -> Linear without the flatten pass (dense NHWC conv output + K-permuted weight panels)
+    POOL_CODES: bool = True          # training: a fused conv + pool stores the pooled map and 2-bit arg-max codes, not the un-pooled activation
+    FUSE_POOL: bool = True           # inference: fold MaxPool2d(2,2) into the preceding conv's epilogue where the geometry allows
+    FC_NORM_IN_WGRAD: int = 1 << 26  # Linear layers with at least this many weights: yolo_wgrad also sums the squares of the gradient it stores
+    # ---- the schedule of the backward pass
+    WGRAD_STREAM: bool = True        # weight gradients run on a second HIP stream beside the data-gradient chain (they are off its critical path)
+    SIDE_LOW: bool = True            # ... of the lowest scheduling priority: the dispatcher prefers the data-gradient chain (12.73 -> 12.55 ms per step)
+    WGRAD_SLABS: bool = False        # pipelined weight-gradient kernel: partial tiles as slabs summed in fixed order instead of fp32 atomics (bit-reproducible,
+                                     # 13-16 % faster per launch alone, slower inside the two-stream step: 12.06 -> 12.28 ms)
+    WGRAD_PIPE: bool = True          # weight gradient of the big deep 3x3 layers through wgrad_pipe.hip (yolo_wgrad_desc.variant = 5)
+
+
+CONFIG = EngineConfig()
+SWITCHES = frozenset(f.name for f in fields(EngineConfig))
