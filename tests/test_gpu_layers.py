@@ -689,6 +689,13 @@ def test_persistent_kernel_equals_the_pipelined_one(cin, cout, k, epi, tpx):
     assert torch.isfinite(got.float()).all()
     assert torch.equal(got, ref), (got.float() - ref.float()).abs().max().item()
     assert torch.equal(run(("tile", hint, 2, 0 if tpx == 224 else tpx)), ref)          # the other tile order
+    if cout % 256 == 0 and epi in ("lrelu", "none", "gate") and hint == 20 and (k * k * cin // 32) % 4 == 0 and k * k * cin // 32 >= 24:
+        # K ranges as extra tiles, partial tiles stored as fp32 slabs, fixed-order sum in yolo_igemm_finish: equal to the slab form of the
+        # pipelined kernel bit for bit (same MFMAs per range, same order of the ranges), and within rounding of the un-split launch
+        sl = run(("slabs", 20, 2, tpx))
+        assert torch.equal(sl, run(("slabs", 15, 2, tpx)))
+        assert torch.equal(sl, run(("slabs", 20, 2, tpx)))
+        _close(sl.permute(0, 3, 1, 2), ref.permute(0, 3, 1, 2).float(), 2.0, "K slabs vs one launch")
     assert torch.equal(a_out.view()[:, 0], torch.full_like(a_out.view()[:, 0], 7.0))   # the halo is never written
 
 

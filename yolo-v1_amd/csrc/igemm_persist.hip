@@ -148,7 +148,10 @@ __device__ __forceinline__ void row_swap4(f32x4 &x, f32x4 &y)
 }
 
 // CODES (with POOL): training's pooled map + 2-bit arg-max codes (pool2 = 3), in its own instantiation
-template <int NTILES, bool POOL, int DGRAD, bool CODES = false>
+// SLAB: split-K -- a "tile" is (channel tile, pixel tile, K range); every range STORES its partial tile, fp32, densely into slab
+// `range` of the output (yolo_igemm_finish adds the slabs in fixed order and applies the layer's epilogue: deterministic).  The deep-K,
+// few-pixel layers (7x7 maps: 64 tiles of 256 x 196 for 256 CUs) fill the chip that way.
+template <int NTILES, bool POOL, int DGRAD, bool CODES = false, bool SLAB = false>
 __global__ void __launch_bounds__(512, 2) igemm_persist_kernel(const IgemmParams p)
 {
     using C = PersistCfg<NTILES>;
@@ -174,16 +177,22 @@ __global__ void __launch_bounds__(512, 2) igemm_persist_kernel(const IgemmParams
 #else
 #define PSTAMP(i) do { } while (0)
 #endif
-    const int T = p.n_co_tiles * p.n_px_tiles;
+    const int S = SLAB ? p.pool_tiles_x : 1;              // K ranges (the launch passes the count in a field the pooled epilogue of igemm.hip owns)
+    const int T = p.n_co_tiles * p.n_px_tiles * S;
     const int G = gridDim.x;
     const int n_mine = (T - (int)blockIdx.x + G - 1) / G;
     const int tpv = p.tpx_valid;
 
     // tile i of this workgroup -> (first channel, first pixel); XCD-aware bijective map of the virtual block id (igemm.hip)
-    auto tile_of = [&](int i, int &co0, unsigned &px0) {
+    auto tile_of = [&](int i, int &co0, unsigned &px0, int &ks) {
         const int v = (int)blockIdx.x + i * G;
         const int q = T >> 3, r = T & 7, xcd = v & 7, k = v >> 3;
-        const int bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+        int bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+        ks = 0;
+        if constexpr (SLAB) {            // the K ranges of one output tile are neighbours: they run at the same time and share its operands in L2
+            ks = bid % S;
+            bid /= S;
+        }
         const int co_tile = p.px_fastest ? bid / p.n_px_tiles : bid % p.n_co_tiles;
         const int px_tile = p.px_fastest ? bid % p.n_px_tiles : bid / p.n_co_tiles;
         co0 = co_tile * TCO;
@@ -214,7 +223,7 @@ __global__ void __launch_bounds__(512, 2) igemm_persist_kernel(const IgemmParams
             const long aux_e = (long)n * p.aux_img_stride + (long)oy * p.aux_row_stride + (long)ox * p.aux_px_stride + p.aux_off;
             uint4 ent;
             ent.x = (unsigned)(in_e * 2);
-            ent.y = (unsigned)(out_e * 2);
+            ent.y = (unsigned)(out_e * (SLAB ? 4 : 2));
             ent.z = (unsigned)(aux_e * 2);
             ent.w = 0;
             *reinterpret_cast<uint4 *>(tab + (buf * 256 + tid) * 4) = ent;
@@ -244,12 +253,11 @@ __global__ void __launch_bounds__(512, 2) igemm_persist_kernel(const IgemmParams
         }
     };
 
-    const int nk = p.nk;
+    const int nk = SLAB ? p.nk_per_split : p.nk;          // K steps per tile
     const int cpt = p.tap_len / BK;
     // scalar staging state of the tile being STAGED (the current tile, or the next one in a tile's last three steps)
     unsigned a_soff = 0;          // byte offset of the step's weight columns + of the tile's first weight row
     int c0 = 0, ky = 0, kx = 0;
-    (void)cpt;
 
     auto stage = [&](int buf) {
         char *sb = stage_base + buf * STAGE_BYTES + wave * 1024;
@@ -273,9 +281,13 @@ __global__ void __launch_bounds__(512, 2) igemm_persist_kernel(const IgemmParams
         kx = w1 ? 0 : kx;
         ky += w1;
     };
-    auto stage_reset = [&](int co0) {
-        a_soff = (unsigned)((long)co0 * p.Ktot * 2);
-        c0 = 0; ky = 0; kx = 0;
+    auto stage_reset = [&](int co0, int ks) {
+        const int kbeg = ks * nk;                            // first K step of the range (0 without split-K)
+        a_soff = (unsigned)((long)co0 * p.Ktot * 2) + (unsigned)kbeg * (BK * 2);
+        const int tap = kbeg / cpt;
+        c0 = (kbeg - tap * cpt) * BK;
+        ky = tap / p.KW;
+        kx = tap - ky * p.KW;
     };
 
     // fragment read offsets: 16 rows further = 4 bank rows (1 KB) further with the same swizzle key -> one base register per operand,
@@ -286,9 +298,9 @@ __global__ void __launch_bounds__(512, 2) igemm_persist_kernel(const IgemmParams
     f32x4 acc[MT][NT0];      // (never zero-filled: the MFMAs of a tile's step 0 take the constant 0 as their C operand)
 
     // ---- prologue: table + bias stash of tile 0, its first D stages in flight, stage 0 landed and visible
-    int co0_cur;
+    int co0_cur, ks_cur;
     unsigned px0_cur;
-    tile_of(0, co0_cur, px0_cur);
+    tile_of(0, co0_cur, px0_cur, ks_cur);
     build_table(0, px0_cur);
     const bool has_bias = p.epilogue == YOLO_EPI_BIAS || p.epilogue == YOLO_EPI_BIAS_LRELU || p.epilogue == YOLO_EPI_BIAS_ADD_LRELU;
     auto load_stash = [&](int co0) {
@@ -299,7 +311,7 @@ __global__ void __launch_bounds__(512, 2) igemm_persist_kernel(const IgemmParams
     load_stash(co0_cur);
     __syncthreads();
     load_b_voff(0);
-    stage_reset(co0_cur);
+    stage_reset(co0_cur, ks_cur);
 #pragma unroll
     for (int s0 = 0; s0 < D; ++s0) stage(s0);
     wait_vmcnt<(D - 1) * LOADS>();
@@ -375,12 +387,13 @@ __global__ void __launch_bounds__(512, 2) igemm_persist_kernel(const IgemmParams
         auto step_x = [&](auto zc, int nst, int rbuf, int lbuf, bf16x8(&ca)[MT], bf16x8(&cb)[NT0], bf16x8(&na)[MT], bf16x8(&nb)[NT0]) {
             // stores of the last epilogue: pooled NTG (one per column), else NTG per PAIR of channel tiles that exists
             if (nst == 0) wait_vmcnt<(D - 2) * LOADS>();
+            else if (SLAB) wait_vmcnt<(D - 2) * LOADS + MT * NTG>();      // (one 16-byte fp32 store per accumulator tile)
             else if (POOL ? !CODES : nst <= 2) wait_vmcnt<(D - 2) * LOADS + NTG>();
             else wait_vmcnt<(D - 2) * LOADS + 2 * NTG>();       // (pooled map + code bytes, or two pairs of channel tiles)
             body(zc, rbuf, lbuf, ca, cb, na, nb);
         };
         // ---- epilogue of one tile, from the accumulator registers (lane: pixel column lane & 15, channels 4 * (lane >> 4) + r)
-        auto epilogue = [&](int tb, int co0, int nvi) {
+        auto epilogue = [&](int tb, int co0, int nvi, int ks) {
             // (the accumulators were written by the MFMAs just issued: the compiler's hazard handling does not look into the inline
             // assembly that reads them first -- give the matrix pipe its worst-case drain time)
             asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
@@ -389,7 +402,24 @@ __global__ void __launch_bounds__(512, 2) igemm_persist_kernel(const IgemmParams
             const unsigned *tb_ = tab + tb * 1024;
             const float *st = stash + wave * 64;
             const float slope = p.slope;
-            if constexpr (POOL) {
+            if constexpr (SLAB) {
+                // the partial tile as it stands: a lane's four fp32 values are four consecutive channels of its pixel = one 16-byte store
+                const float *slab = reinterpret_cast<const float *>(p.out) + (long)ks * p.slab_stride;
+                const unsigned chb = (unsigned)((co0 + wco * 64 + g4) * 4);
+#pragma unroll
+                for (int j = 0; j < NTG; ++j) {
+                    const unsigned ob = tb_[(px_lo + j * 16 + (lane & 15)) * 4 + 1] + chb;
+#pragma unroll
+                    for (int i = 0; i < MT; ++i) {
+                        const unsigned w0 = __float_as_uint(acc[i][j][0]), w1 = __float_as_uint(acc[i][j][1]), w2 = __float_as_uint(acc[i][j][2]), w3 = __float_as_uint(acc[i][j][3]);
+                        if (i == 0) store16<0>(slab, ob, w0, w1, w2, w3);
+                        else if (i == 1) store16<64>(slab, ob, w0, w1, w2, w3);
+                        else if (i == 2) store16<128>(slab, ob, w0, w1, w2, w3);
+                        else store16<192>(slab, ob, w0, w1, w2, w3);
+                    }
+                }
+                (void)nvi; (void)st; (void)slope;
+            } else if constexpr (POOL) {
                 const int e = lane & 3;
                 if constexpr (CODES) {
                     // pool2 = 3: besides the pooled map, WHICH window element was the maximum (2 bits per channel; a lane's four channels
@@ -535,9 +565,9 @@ __global__ void __launch_bounds__(512, 2) igemm_persist_kernel(const IgemmParams
         int nst = 0;                                        // stores of the previous epilogue, in channel tiles (0: none yet)
         for (int ti = 0; ti < n_mine; ++ti) {
             const int tn = ti + 1 < n_mine ? ti + 1 : ti;
-            int co0_next;
+            int co0_next, ks_next;
             unsigned px0_next;
-            tile_of(tn, co0_next, px0_next);
+            tile_of(tn, co0_next, px0_next, ks_next);
             step_x(ZeroC{}, nst, rbuf, lbuf, a0, b0, a1, b1);        // step 0
             adv();
             // every wave is past the previous tile's epilogue (barrier of step 0): its table buffer is free for tile ti + 1
@@ -555,7 +585,7 @@ __global__ void __launch_bounds__(512, 2) igemm_persist_kernel(const IgemmParams
             adv();
             // the next tile's first D stages ride under this tile's last D steps
             load_b_voff((ti + 1) & 1);
-            stage_reset(co0_next);
+            stage_reset(co0_next, ks_next);
             step(rbuf, lbuf, a1, b1, a0, b0);               // step nk-3
             adv();
             step(rbuf, lbuf, a0, b0, a1, b1);               // step nk-2
@@ -569,7 +599,8 @@ __global__ void __launch_bounds__(512, 2) igemm_persist_kernel(const IgemmParams
 #endif
             // channel tiles (of 16) this wave holds inside Cout: 4 but for a ragged last tile (Cout % 16 == 0, host-checked)
             nst = __builtin_amdgcn_readfirstlane(min(4, max(0, (p.Cout - co0_cur - wco * 64) >> 4)));
-            epilogue(ti & 1, co0_cur, nst);
+            epilogue(ti & 1, co0_cur, nst, ks_cur);
+            ks_cur = ks_next;
 #ifdef IGEMM_STAMPS
             if (ti == 0) PSTAMP(3);
             if (ti == 1) PSTAMP(5);
@@ -604,8 +635,8 @@ static void magic_u31(unsigned d, unsigned &magic, unsigned &shift)
     shift = l - 1;
 }
 
-template <int NTILES, bool POOL, int DGRAD, bool CODES = false>
-static int persist_launch(const IgemmParams &p, hipStream_t s)
+template <int NTILES, bool POOL, int DGRAD, bool CODES = false, bool SLAB = false>
+static int persist_launch(const IgemmParams &p, int splits, hipStream_t s)
 {
     using C = PersistCfg<NTILES>;
     static bool attr_done[64] = {};
@@ -613,7 +644,7 @@ static int persist_launch(const IgemmParams &p, hipStream_t s)
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
     if (!attr_done[dev]) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&igemm_persist_kernel<NTILES, POOL, DGRAD, CODES>), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&igemm_persist_kernel<NTILES, POOL, DGRAD, CODES, SLAB>), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
         if (e != hipSuccess) return fail((int)e, "yolo_igemm: hipFuncSetAttribute(%d B LDS): %s", C::LDS_BYTES, hipGetErrorString(e));
         int n = 0;
         if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
@@ -630,19 +661,24 @@ static int persist_launch(const IgemmParams &p, hipStream_t s)
     magic_u31((unsigned)p.HoWo, q.div_hw_magic, q.div_hw_shift);
     magic_u31((unsigned)p.Wo, q.div_w_magic, q.div_w_shift);
     magic_u31((unsigned)p.Wo / 2, q.div_hw2_magic, q.div_hw2_shift);
-    const long tiles = (long)q.n_co_tiles * q.n_px_tiles;
+    q.nk_per_split = q.nk / (SLAB ? splits : 1);
+    const long tiles = (long)q.n_co_tiles * q.n_px_tiles * (SLAB ? splits : 1);
     const int G = (int)std::min<long>(tiles, cus[dev]);
-    hipLaunchKernelGGL((igemm_persist_kernel<NTILES, POOL, DGRAD, CODES>), dim3(G), dim3(C::NTHR), C::LDS_BYTES, s, q);
+    q.pool_tiles_x = SLAB ? splits : 1;
+    hipLaunchKernelGGL((igemm_persist_kernel<NTILES, POOL, DGRAD, CODES, SLAB>), dim3(G), dim3(C::NTHR), C::LDS_BYTES, s, q);
     return check_launch("yolo_igemm (persistent)");
 }
 
 int igemm_persist_launch(const IgemmParams &p, int hint, int splits, hipStream_t s)
 {
-    if (p.stats || p.w_blocked || splits > 1 || p.slab_stride || p.out_fp32 || p.px_begin)
-        return fail(YOLO_E_UNSUPPORTED, "yolo_igemm: tile_hint %d is a plain bf16 launch (no bn_stats, blocked weights, split-K, fp32 output, pixel range)", hint);
+    const bool slab = splits > 1;
+    if (p.stats || p.w_blocked || p.px_begin || (slab ? (!p.slab_stride || !p.out_fp32 || p.epilogue != YOLO_EPI_NONE || p.pool) : (p.slab_stride || p.out_fp32)))
+        return fail(YOLO_E_UNSUPPORTED, "yolo_igemm: tile_hint %d is a bf16 launch, or split-K into fp32 slabs (split_slabs = 1, epilogue NONE); no bn_stats, blocked weights, pixel range", hint);
     if (p.tap_len % 32) return fail(YOLO_E_UNSUPPORTED, "yolo_igemm: tile_hint %d needs tap_len %% 32 == 0", hint);
-    const long nk = p.Ktot / 32;
-    if (nk % 2 || nk < 6) return fail(YOLO_E_UNSUPPORTED, "yolo_igemm: tile_hint %d needs an even number (>= 6) of 32-deep K steps", hint);
+    const long nk_all = p.Ktot / 32;
+    if (nk_all % splits) return fail(YOLO_E_UNSUPPORTED, "yolo_igemm: tile_hint %d splits K into equal ranges", hint);
+    const long nk = nk_all / splits;
+    if (nk % 2 || nk < 6) return fail(YOLO_E_UNSUPPORTED, "yolo_igemm: tile_hint %d needs an even number (>= 6) of 32-deep K steps per range", hint);
     if (p.epilogue < YOLO_EPI_NONE || p.epilogue > YOLO_EPI_BIAS_ADD_LRELU) return fail(YOLO_E_UNSUPPORTED, "yolo_igemm: tile_hint %d has no epilogue %d", hint, p.epilogue);
     if (!(p.slope >= 0.0f && p.slope <= 1.0f)) return fail(YOLO_E_UNSUPPORTED, "yolo_igemm: tile_hint %d needs 0 <= slope <= 1", hint);
     if (p.Cout > 256 && p.Cout % 256) return fail(YOLO_E_UNSUPPORTED, "yolo_igemm: tile_hint %d needs Cout <= 256 or Cout %% 256 == 0", hint);
@@ -651,7 +687,7 @@ int igemm_persist_launch(const IgemmParams &p, int hint, int splits, hipStream_t
     // every operand is addressed as base + 32-bit byte offset
     const long n_img = p.M / p.HoWo + 1;
     const long in_bytes = (n_img * p.in_img_stride + (long)p.KH * p.in_row_stride) * 2, w_bytes = (long)p.Cout * p.Ktot * 2;
-    const long out_bytes = (n_img * p.out_img_stride + p.out_off) * 2, aux_bytes = p.aux ? (n_img * p.aux_img_stride + p.aux_off) * 2 : 0;
+    const long out_bytes = (n_img * p.out_img_stride + p.out_off) * (slab ? 4 : 2), aux_bytes = p.aux ? (n_img * p.aux_img_stride + p.aux_off) * 2 : 0;
     if (in_bytes >= (1L << 32) || w_bytes >= (1L << 32) || out_bytes >= (1L << 32) || aux_bytes >= (1L << 32))
         return fail(YOLO_E_UNSUPPORTED, "yolo_igemm: tile_hint %d addresses operands below 4 GB", hint);
     if ((p.out_off | p.out_px_stride | p.out_row_stride) & 3 || (p.out_img_stride & 3))
@@ -664,12 +700,14 @@ int igemm_persist_launch(const IgemmParams &p, int hint, int splits, hipStream_t
             return fail(YOLO_E_UNSUPPORTED, "yolo_igemm: the pooled epilogue of tile_hint 21 needs pool2 = 1 or 3, rows of 112, 56 or 28 pixels and whole 224-pixel tiles");
         if (p.pool == 3 && ((p.out_off | p.out_px_stride | p.out_row_stride) & 7 || (p.out_img_stride & 7) || (p.Cout & 7)))
             return fail(YOLO_E_UNSUPPORTED, "yolo_igemm: pool2 = 3 needs Cout and the output strides in multiples of 8");
-        return p.pool == 3 ? persist_launch<14, true, 0, true>(p, s) : persist_launch<14, true, 0>(p, s);
+        return p.pool == 3 ? persist_launch<14, true, 0, true>(p, 1, s) : persist_launch<14, true, 0>(p, 1, s);
     }
+    if (slab && p.Cout % 256) return fail(YOLO_E_UNSUPPORTED, "yolo_igemm: tile_hint %d splits K only for Cout %% 256 == 0", hint);
+    if (slab) return hint == 20 ? persist_launch<13, false, 0, false, true>(p, splits, s) : persist_launch<14, false, 0, false, true>(p, splits, s);
     const int dg = p.epilogue == YOLO_EPI_MUL_DLRELU ? 1 : (p.epilogue == YOLO_EPI_BIAS_ADD_LRELU ? 2 : 0);
     switch (hint) {
-    case 20: return dg == 1 ? persist_launch<13, false, 1>(p, s) : (dg == 2 ? persist_launch<13, false, 2>(p, s) : persist_launch<13, false, 0>(p, s));
-    case 21: return dg == 1 ? persist_launch<14, false, 1>(p, s) : (dg == 2 ? persist_launch<14, false, 2>(p, s) : persist_launch<14, false, 0>(p, s));
+    case 20: return dg == 1 ? persist_launch<13, false, 1>(p, 1, s) : (dg == 2 ? persist_launch<13, false, 2>(p, 1, s) : persist_launch<13, false, 0>(p, 1, s));
+    case 21: return dg == 1 ? persist_launch<14, false, 1>(p, 1, s) : (dg == 2 ? persist_launch<14, false, 2>(p, 1, s) : persist_launch<14, false, 0>(p, 1, s));
     }
     return fail(YOLO_E_ARG, "yolo_igemm: tile_hint %d is not a persistent configuration", hint);
 }

@@ -291,6 +291,11 @@ def _tune(L_, d: IgemmDesc, inp, w, bias, aux, out, st, what):
             and d.epilogue in (EPI_NONE, EPI_BIAS, EPI_BIAS_LRELU, EPI_MUL_DLRELU)):
         for c, S, tpv in ((11, 2, 0), (5, 2, 0), (3, 2, 0), (14, 4, tile_px), (15, 4, tile_px), (15, 2, tile_px), (12, 4, 0), (11, 4, 0)):
             consider(("slabs", c, S, tpv))
+        if d.Cout % 256 == 0 and d.tap_len % 32 == 0:
+            for S in (2, 4, 8):       # the persistent kernel, K ranges as extra tiles (each range: an even number >= 6 of K steps)
+                nks = d.KH * d.KW * d.tap_len // 32
+                if nks % S == 0 and (nks // S) % 2 == 0 and nks // S >= 6:
+                    consider(("slabs", 20, S, tile_px))
     d.bn_stats = stats_ptr
     if not times:
         return (0, 0)
