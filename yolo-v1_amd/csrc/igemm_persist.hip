@@ -28,7 +28,7 @@ struct PersistCfg {
     static constexpr int TCO = 256, NTILES = NTILES_, NST = 4, BK = 32;
     static constexpr int TPX = 16 * NTILES;
     static constexpr int WCO = 4, NW = 8, NTHR = 512;
-    static constexpr int MT = 4, NT0 = 7, NT1 = NTILES - 7;
+    static constexpr int NT0 = 7, NT1 = NTILES - 7;
     static constexpr int A_BYTES = TCO * BK * 2;
     static constexpr int B_BYTES = 256 * BK * 2;
     static constexpr int STAGE_BYTES = A_BYTES + B_BYTES;
@@ -151,12 +151,15 @@ __device__ __forceinline__ void row_swap4(f32x4 &x, f32x4 &y)
 // SLAB: split-K -- a "tile" is (channel tile, pixel tile, K range); every range STORES its partial tile, fp32, densely into slab
 // `range` of the output (yolo_igemm_finish adds the slabs in fixed order and applies the layer's epilogue: deterministic).  The deep-K,
 // few-pixel layers (7x7 maps: 64 tiles of 256 x 196 for 256 CUs) fill the chip that way.
-template <int NTILES, bool POOL, int DGRAD, bool CODES = false, bool SLAB = false>
+// MT: 16-channel accumulator tiles per wave (4; 3 for Cout = 192 -- the pooled epilogues only)
+template <int NTILES, bool POOL, int DGRAD, bool CODES = false, bool SLAB = false, int MT = 4>
 __global__ void __launch_bounds__(512, 2) igemm_persist_kernel(const IgemmParams p)
 {
     using C = PersistCfg<NTILES>;
-    constexpr int TPX = C::TPX, BK = C::BK, NW = C::NW, WCO = C::WCO, MT = C::MT, NT0 = C::NT0, NT1 = C::NT1, NST = C::NST;
-    constexpr int A_BYTES = C::A_BYTES, STAGE_BYTES = C::STAGE_BYTES, LOADS = C::LOADS, D = C::D, TCO = C::TCO;
+    constexpr int TPX = C::TPX, BK = C::BK, NW = C::NW, WCO = C::WCO, NT0 = C::NT0, NT1 = C::NT1, NST = C::NST;
+    constexpr int A_BYTES = C::A_BYTES, STAGE_BYTES = C::STAGE_BYTES, LOADS = C::LOADS, D = C::D;
+    constexpr int WCH = MT * 16;          // channels per wave (64; 48 with MT = 3: 192-channel layers without a quarter of the MFMAs on padding)
+    constexpr int TCO = WCO * WCH;        // channels per tile (the stage still holds 256 weight rows: the surplus rows are clamped duplicates)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     unsigned *tab = reinterpret_cast<unsigned *>(smem);                         // [2][256][4]
     float *stash = reinterpret_cast<float *>(smem + 2 * C::TABLE_BYTES);        // [NW][64]
@@ -292,7 +295,7 @@ __global__ void __launch_bounds__(512, 2) igemm_persist_kernel(const IgemmParams
 
     // fragment read offsets: 16 rows further = 4 bank rows (1 KB) further with the same swizzle key -> one base register per operand,
     // the tiles as immediate offsets
-    const int a_rd0 = lds_off<BK, true>(wco * 64 + (lane & 15), lane >> 4);
+    const int a_rd0 = lds_off<BK, true>(wco * WCH + (lane & 15), lane >> 4);
     const int b_rd0 = A_BYTES + lds_off<BK, true>(px_lo + (lane & 15), lane >> 4);
 
     f32x4 acc[MT][NT0];      // (never zero-filled: the MFMAs of a tile's step 0 take the constant 0 as their C operand)
@@ -305,8 +308,8 @@ __global__ void __launch_bounds__(512, 2) igemm_persist_kernel(const IgemmParams
     const bool has_bias = p.epilogue == YOLO_EPI_BIAS || p.epilogue == YOLO_EPI_BIAS_LRELU || p.epilogue == YOLO_EPI_BIAS_ADD_LRELU;
     auto load_stash = [&](int co0) {
         const int lane = fresh_lane();
-        const int ch = co0 + wco * 64 + lane;
-        stash[wave * 64 + lane] = (has_bias && ch < p.Cout) ? p.bias[ch] : 0.0f;
+        const int ch = co0 + wco * WCH + lane;
+        stash[wave * 64 + lane] = (has_bias && lane < WCH && ch < p.Cout) ? p.bias[ch] : 0.0f;
     };
     load_stash(co0_cur);
     __syncthreads();
@@ -405,7 +408,7 @@ __global__ void __launch_bounds__(512, 2) igemm_persist_kernel(const IgemmParams
             if constexpr (SLAB) {
                 // the partial tile as it stands: a lane's four fp32 values are four consecutive channels of its pixel = one 16-byte store
                 const float *slab = reinterpret_cast<const float *>(p.out) + (long)ks * p.slab_stride;
-                const unsigned chb = (unsigned)((co0 + wco * 64 + g4) * 4);
+                const unsigned chb = (unsigned)((co0 + wco * WCH + g4) * 4);
 #pragma unroll
                 for (int j = 0; j < NTG; ++j) {
                     const unsigned ob = tb_[(px_lo + j * 16 + (lane & 15)) * 4 + 1] + chb;
@@ -429,8 +432,8 @@ __global__ void __launch_bounds__(512, 2) igemm_persist_kernel(const IgemmParams
                     f32x4 bsa[MT];
 #pragma unroll
                     for (int i = 0; i < MT; ++i) bsa[i] = *reinterpret_cast<const f32x4 *>(st + i * 16 + g4);
-                    const unsigned chb = (unsigned)((co0 + wco * 64 + e * 16 + g4) * 2);
-                    const unsigned cdb = (unsigned)((co0 + wco * 64 + e * 16) >> 2) + (unsigned)(lane >> 4);       // byte of this lane's code
+                    const unsigned chb = (unsigned)((co0 + wco * WCH + e * 16 + g4) * 2);
+                    const unsigned cdb = (unsigned)((co0 + wco * WCH + e * 16) >> 2) + (unsigned)(lane >> 4);       // byte of this lane's code
                     const bool lrelu = p.epilogue == YOLO_EPI_BIAS_LRELU;
 #pragma unroll
                     for (int j = 0; j < NTG; ++j) {
@@ -468,7 +471,7 @@ __global__ void __launch_bounds__(512, 2) igemm_persist_kernel(const IgemmParams
                 } else {
                 // bias of the channel tile this lane stores (tile e of the wave's four)
                 const f32x4 bs = *reinterpret_cast<const f32x4 *>(st + e * 16 + g4);
-                const unsigned chb = (unsigned)((co0 + wco * 64 + e * 16 + g4) * 2);
+                const unsigned chb = (unsigned)((co0 + wco * WCH + e * 16 + g4) * 2);
 #pragma unroll
                 for (int j = 0; j < NTG; ++j) {
                     const unsigned ob = tb_[(px_lo + j * 16 + (lane & 15)) * 4 + 1] + chb;
@@ -502,7 +505,7 @@ __global__ void __launch_bounds__(512, 2) igemm_persist_kernel(const IgemmParams
                     bs[pr][0] = *reinterpret_cast<const f32x4 *>(st + pr * 32 + cl);
                     bs[pr][1] = *reinterpret_cast<const f32x4 *>(st + pr * 32 + cl + 4);
                 }
-                const unsigned chb = (unsigned)((co0 + wco * 64 + cl) * 2);
+                const unsigned chb = (unsigned)((co0 + wco * WCH + cl) * 2);
                 const int my_tile = g & 1;                                   // + 2 * pair: the channel tile this lane stores
                 const bool lrelu = p.epilogue == YOLO_EPI_BIAS_LRELU;
 #pragma unroll
@@ -598,7 +601,7 @@ __global__ void __launch_bounds__(512, 2) igemm_persist_kernel(const IgemmParams
             if (ti == n_mine - 1) PSTAMP(6);
 #endif
             // channel tiles (of 16) this wave holds inside Cout: 4 but for a ragged last tile (Cout % 16 == 0, host-checked)
-            nst = __builtin_amdgcn_readfirstlane(min(4, max(0, (p.Cout - co0_cur - wco * 64) >> 4)));
+            nst = __builtin_amdgcn_readfirstlane(min(MT, max(0, (p.Cout - co0_cur - wco * WCH) >> 4)));
             epilogue(ti & 1, co0_cur, nst, ks_cur);
             ks_cur = ks_next;
 #ifdef IGEMM_STAMPS
@@ -635,7 +638,7 @@ static void magic_u31(unsigned d, unsigned &magic, unsigned &shift)
     shift = l - 1;
 }
 
-template <int NTILES, bool POOL, int DGRAD, bool CODES = false, bool SLAB = false>
+template <int NTILES, bool POOL, int DGRAD, bool CODES = false, bool SLAB = false, int MT = 4>
 static int persist_launch(const IgemmParams &p, int splits, hipStream_t s)
 {
     using C = PersistCfg<NTILES>;
@@ -644,7 +647,7 @@ static int persist_launch(const IgemmParams &p, int splits, hipStream_t s)
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
     if (!attr_done[dev]) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&igemm_persist_kernel<NTILES, POOL, DGRAD, CODES, SLAB>), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&igemm_persist_kernel<NTILES, POOL, DGRAD, CODES, SLAB, MT>), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
         if (e != hipSuccess) return fail((int)e, "yolo_igemm: hipFuncSetAttribute(%d B LDS): %s", C::LDS_BYTES, hipGetErrorString(e));
         int n = 0;
         if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
@@ -652,7 +655,7 @@ static int persist_launch(const IgemmParams &p, int splits, hipStream_t s)
         attr_done[dev] = true;
     }
     IgemmParams q = p;
-    q.n_co_tiles = (p.Cout + C::TCO - 1) / C::TCO;
+    q.n_co_tiles = (p.Cout + 64 * MT - 1) / (64 * MT);
     if (POOL) q.tpx_valid = C::TPX;
     if (q.tpx_valid <= 0 || q.tpx_valid > C::TPX) q.tpx_valid = C::TPX;
     q.n_px_tiles = (int)((p.M + q.tpx_valid - 1) / q.tpx_valid);
@@ -665,7 +668,7 @@ static int persist_launch(const IgemmParams &p, int splits, hipStream_t s)
     const long tiles = (long)q.n_co_tiles * q.n_px_tiles * (SLAB ? splits : 1);
     const int G = (int)std::min<long>(tiles, cus[dev]);
     q.pool_tiles_x = SLAB ? splits : 1;
-    hipLaunchKernelGGL((igemm_persist_kernel<NTILES, POOL, DGRAD, CODES, SLAB>), dim3(G), dim3(C::NTHR), C::LDS_BYTES, s, q);
+    hipLaunchKernelGGL((igemm_persist_kernel<NTILES, POOL, DGRAD, CODES, SLAB, MT>), dim3(G), dim3(C::NTHR), C::LDS_BYTES, s, q);
     return check_launch("yolo_igemm (persistent)");
 }
 
@@ -700,6 +703,8 @@ int igemm_persist_launch(const IgemmParams &p, int hint, int splits, hipStream_t
             return fail(YOLO_E_UNSUPPORTED, "yolo_igemm: the pooled epilogue of tile_hint 21 needs pool2 = 1 or 3, rows of 112, 56 or 28 pixels and whole 224-pixel tiles");
         if (p.pool == 3 && ((p.out_off | p.out_px_stride | p.out_row_stride) & 7 || (p.out_img_stride & 7) || (p.Cout & 7)))
             return fail(YOLO_E_UNSUPPORTED, "yolo_igemm: pool2 = 3 needs Cout and the output strides in multiples of 8");
+        if (p.Cout > 128 && p.Cout <= 192)        // three 16-channel tiles per wave: no MFMA spent on 64 channels of padding
+            return p.pool == 3 ? persist_launch<14, true, 0, true, false, 3>(p, 1, s) : persist_launch<14, true, 0, false, false, 3>(p, 1, s);
         return p.pool == 3 ? persist_launch<14, true, 0, true>(p, 1, s) : persist_launch<14, true, 0>(p, 1, s);
     }
     if (slab && p.Cout % 256) return fail(YOLO_E_UNSUPPORTED, "yolo_igemm: tile_hint %d splits K only for Cout %% 256 == 0", hint);
