@@ -119,6 +119,8 @@ def _launch_ranks(n: int) -> None:
     import socket
     import subprocess
     have = torch.cuda.device_count()          # counts devices without initialising the GPU
+    if os.environ.get("BENCH_REHEARSE") == "1":
+        have = max(have * n, n) if have else 0  # rehearsal of the N-rank path on ONE GPU (gloo; see main): every rank uses device 0
     if have < n:
         print(f"bench.py: --gpus {n} but only {have} GPU(s) visible", file=sys.stderr)
         raise SystemExit(2)
@@ -204,10 +206,19 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != a.gpus:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    # BENCH_REHEARSE=1: the whole N-rank code path (launcher, sharded inputs, gradient arena + bucketed all-reduce, max-over-ranks timing,
+    # rank-0 JSON) on a box with ONE GPU -- every rank on device 0, gloo instead of RCCL (which refuses to use a device twice).  The numbers
+    # mean nothing (the ranks share the GPU); the run shows that the path works.  Marked in the JSON line.
+    rehearse = os.environ.get("BENCH_REHEARSE") == "1"
+    if rehearse:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     use_dist = "RANK" in os.environ and "MASTER_PORT" in os.environ     # launched by torch.distributed.run
-    if use_dist:
+    if use_dist and rehearse:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo")
+    elif use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         # RCCL prints a version banner on STDOUT when its communicator is created; stdout must carry only the
         # JSON line, so fd 1 points at stderr until the first collective has run
@@ -590,6 +601,7 @@ def main():
                        "global_batch": world * B, "per_gpu_batch": B, "weights": "random init (torch default, seed 0)",
                        "flops_per_image": 40.57e9, "parallelism": f"dp{world}" if world > 1 else "single"},
             "roofline": roof, "cpu_baseline": cpu, "sustained": sustained, "first_forward_ms": round(first_forward_ms, 1),
+            **({"rehearsal": "BENCH_REHEARSE=1: all ranks on ONE GPU over gloo -- a test of the N-rank code path, not a measurement"} if rehearse else {}),
             "train": train, "nms": nms, "preprocess": pre, "resnet50_variant": resnet,
         }
         print(json.dumps(out))
