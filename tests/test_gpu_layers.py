@@ -668,7 +668,8 @@ def _persist_problem(N, cin, cout, k, H, W, epi, pool=0, stride=1):
 
 @pytest.mark.parametrize("cin,cout,k,epi,tpx", [(64, 512, 3, "lrelu", 196), (64, 512, 3, "lrelu", 208), (192, 256, 1, "lrelu", 196), (256, 512, 1, "gate", 196),
                                                  (128, 256, 3, "gate", 208), (64, 192, 3, "lrelu", 196), (512, 256, 1, "none", 100), (64, 256, 3, "lrelu", 224),
-                                                 (256, 1024, 1, "add", 208), (192, 256, 1, "add", 224)])
+                                                 (256, 1024, 1, "add", 208), (192, 256, 1, "add", 224), (128, 128, 3, "lrelu", 196), (64, 64, 3, "gate", 208),
+                                                 (256, 512, 3, "lrelu", -2), (512, 256, 1, "lrelu", -1)])
 def test_persistent_kernel_equals_the_pipelined_one(cin, cout, k, epi, tpx):
     """igemm_persist.hip (tile_hint 20 / 21): several tiles per workgroup in ONE software pipeline (61 440 pixels: 296-615 pixel tiles x
     1-2 channel tiles for 256 workgroups), table of the next tile built under the K loop, epilogue straight out of the accumulator
@@ -676,7 +677,14 @@ def test_persistent_kernel_equals_the_pipelined_one(cin, cout, k, epi, tpx):
     run-to-run differences: the duplicate stores of a tile's idle pixel slots write identical bits)."""
     from yolo import engine
     from yolo._hip import lib, ptr, stream
-    d, a_in, w, b, aux, a_out = _persist_problem(8, cin, cout, k, 80, 96, epi)
+    if tpx == -2:        # a stride-2 conv (ResNet's downsample / 3x3 s2 layers run these plans), ragged last tile
+        d, a_in, w, b, aux, a_out = _persist_problem(8, cin, cout, k, 80, 96, epi, stride=2)
+        tpx = 196
+    elif tpx == -1:      # fewer tiles than CUs: one image, 5 pixel tiles -- every workgroup has ONE tile, most CUs none
+        d, a_in, w, b, aux, a_out = _persist_problem(1, cin, cout, k, 28, 28, epi)
+        tpx = 196
+    else:
+        d, a_in, w, b, aux, a_out = _persist_problem(8, cin, cout, k, 80, 96, epi)
     hint = 21 if tpx == 224 else 20
 
     def run(pl):
