@@ -647,19 +647,24 @@ class Plan:
             self.arena[self._arena_w_end:].zero_()      # bias gradients are accumulated with atomics
         grads: dict[int, tuple] = {}
         nl = len(self.layers)
-        # one zero-filled fp32 scratch for the whole pass: the packed conv weight gradients (targets of
-        # yolo_wgrad's atomics) and, without an arena, the bias gradients -- one fill instead of ~50
+        # two zero-filled fp32 scratch areas for the whole pass: the packed conv weight gradients (targets of yolo_wgrad's atomics; a buffer
+        # of the workspace, cleared ON THE SIDE STREAM, where its first user runs: 80 MB of fill off the data-gradient chain) and,
+        # without an arena, the bias gradients (fresh every pass: they are handed to autograd) -- two fills instead of ~50
         offs, tot = {}, 0
         for i, L in enumerate(self.layers):
             if L.kind == "conv":
                 offs[("w", i)] = tot
                 tot += _round_up(L.Cout * 7 * 8 * 4 if L.first else L.Cout * L.K * L.K * L.Cin, 64)
+        btot = 0
         if self.arena is None:
             for i, L in enumerate(self.layers):
                 if L.kind in ("conv", "fc"):
-                    offs[("b", i)] = tot
-                    tot += _round_up(L.Cout, 64)
-        scratch = torch.zeros(tot, dtype=torch.float32, device=dev)
+                    offs[("b", i)] = btot
+                    btot += _round_up(L.Cout, 64)
+        scratch = ws["misc"].get("wgrad_scratch")
+        if scratch is None or scratch.numel() < tot:
+            scratch = ws["misc"]["wgrad_scratch"] = torch.empty(max(tot, 1), dtype=torch.float32, device=dev)
+        bscratch = torch.zeros(max(btot, 1), dtype=torch.float32, device=dev)
 
         def grad_tensors(i):
             L = self.layers[i]
@@ -667,7 +672,7 @@ class Plan:
                 dw, db, _, _ = self.arena_views[i]
                 return dw, db
             o = offs[("b", i)]
-            return torch.empty_like(L.weight, dtype=torch.float32), scratch[o: o + L.Cout]
+            return torch.empty_like(L.weight, dtype=torch.float32), bscratch[o: o + L.Cout]
 
         # packed -> OIHW conversion of finished conv gradients is deferred and done for several layers per
         # launch (yolo_unpack_conv_wgrads_multi); gradients become final (and are announced) at the flush
@@ -700,6 +705,9 @@ class Plan:
 
         def _on_side():
             return _on_side_stream(main_t, side_t, self.on_stream_wait if self.arena is not None else None)
+
+        with _on_side():
+            scratch.zero_()
 
         # what each layer's input activation is
         def input_of(li):
