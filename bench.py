@@ -322,10 +322,11 @@ def main():
         crit = YOLOLoss()
         from yolo.optim import Adam
         opt = Adam(model.parameters(), lr=1e-4, weight_decay=5e-4, max_grad_norm=10.0)  # clip_grad_norm_(10) + Adam fused
-        # Adam also refreshes the bf16 operands of the Linear layers in the same pass.  (Round 2 ran their update as a background pass on 64
-        # CUs beside the next forward's conv stack; the persistent conv kernels of round 3 want all 256 CUs -- a workgroup per CU walks
-        # the tiles -- and lose more to the 64 held CUs than the overlap hides: 11.24 ms per step without it, 11.53 with, same process.)
-        opt.attach_plan(model.hip_plan(), overlap=False)
+        # Adam also refreshes the bf16 operands of the Linear layers in the same pass; their update (822 MB of FC1 state) runs as a
+        # background pass on 64 CUs beside the next forward's conv stack.  The persistent conv kernels draw their tiles from a queue
+        # (igemm_persist.hip), so the CUs the background pass holds cost them a share of the chip, not a whole round of tiles:
+        # 11.40 ms per step with the overlap, 11.58 without, same box (with statically assigned tiles it was 11.62 / 11.55).
+        opt.attach_plan(model.hip_plan(), overlap=os.environ.get("BENCH_ADAM_OVERLAP", "1") == "1")
         # data parallel: gradient arena + all-reduce overlapped with the backward pass (FC1's 822 MB first)
         ar = make_grad_reducer(model, dev) if (use_dist and world > 1) else None      # the reducer the shipped training loop uses (nothing to reduce in a world of one)
 

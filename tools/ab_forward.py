@@ -30,4 +30,5 @@ with torch.no_grad():
 for k, v in res.items():
     print(f"{name}={k}: " + " ".join(f"{t:.4f}" for t in v) + f"  ms/forward (min {min(v):.4f})")
 ks = list(outs)
-print("outputs equal:", all(torch.equal(outs[ks[0]], outs[k]) for k in ks[1:]), " max |diff|", max((outs[ks[0]] - outs[k]).abs().max().item() for k in ks[1:]))
+if len(ks) > 1:
+    print("outputs equal:", all(torch.equal(outs[ks[0]], outs[k]) for k in ks[1:]), " max |diff|", max((outs[ks[0]] - outs[k]).abs().max().item() for k in ks[1:]))

@@ -50,6 +50,7 @@ struct IgemmParams {
     double *stats;          // != nullptr: per-channel sum / sum of squares of the (bf16-rounded) outputs, see yolo_igemm_desc.bn_stats
     // igemm_persist.hip: divisions of the address table as multiply-high (floor(n / d) = umulhi(n, magic) >> shift, n < 2^31; magic 0: d = 1)
     unsigned div_hw_magic, div_hw_shift, div_w_magic, div_w_shift, div_hw2_magic, div_hw2_shift;   // d = HoWo, Wo, Wo / 2
+    unsigned *tile_ctr;     // igemm_persist.hip: eight tile counters of this launch (one per XCD label), zero when the kernel starts
 };
 
 #define GLDS16(gptr, lptr) \

@@ -20,6 +20,8 @@
 // the first two K steps behind an epilogue depends on it.
 // Reference arithmetic: nn.Conv2d + nn.LeakyReLU(0.1) (+ nn.MaxPool2d(2,2)), src/yolo/models.py:47-84.
 #include "igemm_common.h"
+#include <atomic>
+#include <mutex>
 
 namespace yolo {
 
@@ -36,7 +38,8 @@ struct PersistCfg {
     static constexpr int LOADS = A_PIECES + B_PIECES;
     static constexpr int TABLE_BYTES = 256 * 16;            // one table: 16 B per pixel slot {in, out, aux byte offsets, -}
     static constexpr int STASH_BYTES = NW * 64 * 4;         // per-wave bias stash
-    static constexpr int LDS_BYTES = 2 * TABLE_BYTES + STASH_BYTES + NST * STAGE_BYTES;
+    static constexpr int MAIL_BYTES = 64;                   // tile numbers drawn from the queue, wave 0 -> all waves
+    static constexpr int LDS_BYTES = 2 * TABLE_BYTES + STASH_BYTES + MAIL_BYTES + NST * STAGE_BYTES;
     static constexpr int D = NST - 1;
     static_assert(NT1 >= 1 && NT1 <= NT0, "pixel group B holds 1 .. 7 columns");
 };
@@ -163,7 +166,8 @@ __global__ void __launch_bounds__(512, 2) igemm_persist_kernel(const IgemmParams
     extern __shared__ __attribute__((aligned(16))) char smem[];
     unsigned *tab = reinterpret_cast<unsigned *>(smem);                         // [2][256][4]
     float *stash = reinterpret_cast<float *>(smem + 2 * C::TABLE_BYTES);        // [NW][64]
-    char *stage_base = smem + 2 * C::TABLE_BYTES + C::STASH_BYTES;
+    int *mail = reinterpret_cast<int *>(smem + 2 * C::TABLE_BYTES + C::STASH_BYTES);     // [2] (read and written between barriers)
+    char *stage_base = smem + 2 * C::TABLE_BYTES + C::STASH_BYTES + C::MAIL_BYTES;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -183,14 +187,22 @@ __global__ void __launch_bounds__(512, 2) igemm_persist_kernel(const IgemmParams
     const int S = SLAB ? p.pool_tiles_x : 1;              // K ranges (the launch passes the count in a field the pooled epilogue of igemm.hip owns)
     const int T = p.n_co_tiles * p.n_px_tiles * S;
     const int G = gridDim.x;
-    const int n_mine = (T - (int)blockIdx.x + G - 1) / G;
     const int tpv = p.tpx_valid;
+    // Tiles are handed out per XCD: workgroups b and b + 8 share an XCD (and its L2), so label x = b & 7 owns one contiguous eighth of
+    // the tile order (igemm.hip's bijective map); a workgroup's FIRST tile is static (number b >> 3 of its label's range), every further
+    // one is drawn from the label's counter in device memory (p.tile_ctr[x], zero at launch).  Static rounds (tile b, b + G, ..) assume
+    // that all G workgroups are resident at once; when something else holds CUs -- RCCL's all-reduce kernels beside the backward pass, a
+    // background optimizer pass -- the workgroups that start late would begin their rounds when the others have finished theirs, up to
+    // twice the time.  Drawn tiles make the launch work-conserving: whoever runs takes the next tile.
+    const int xl = (int)blockIdx.x & 7;
+    const int cnt_x = (T >> 3) + (xl < (T & 7) ? 1 : 0);       // tiles of this label
+    const int nwg_x = (G - xl + 7) >> 3;                       // workgroups of this label = its statically assigned tiles
+    unsigned *const tile_ctr = p.tile_ctr + xl;
 
-    // tile i of this workgroup -> (first channel, first pixel); XCD-aware bijective map of the virtual block id (igemm.hip)
-    auto tile_of = [&](int i, int &co0, unsigned &px0, int &ks) {
-        const int v = (int)blockIdx.x + i * G;
-        const int q = T >> 3, r = T & 7, xcd = v & 7, k = v >> 3;
-        int bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+    // tile j of this label -> (first channel, first pixel, K range)
+    auto tile_of = [&](int j, int &co0, unsigned &px0, int &ks) {
+        const int q = T >> 3, r = T & 7;
+        int bid = (xl < r ? xl * (q + 1) : r * (q + 1) + (xl - r) * q) + j;
         ks = 0;
         if constexpr (SLAB) {            // the K ranges of one output tile are neighbours: they run at the same time and share its operands in L2
             ks = bid % S;
@@ -300,10 +312,37 @@ __global__ void __launch_bounds__(512, 2) igemm_persist_kernel(const IgemmParams
 
     f32x4 acc[MT][NT0];      // (never zero-filled: the MFMAs of a tile's step 0 take the constant 0 as their C operand)
 
-    // ---- prologue: table + bias stash of tile 0, its first D stages in flight, stage 0 landed and visible
+    // The queue.  draw(): wave 0's lane 0 adds 1 to the label's counter (a returning atomic from inline assembly: the compiler does not
+    // know it is in flight, so it inserts no wait; the result register is valid once a vmcnt wait has covered the instruction -- every
+    // K step's counted wait does, two steps later at the latest).  publish(): the same lane puts the drawn number into the LDS mailbox;
+    // the other waves read it behind a barrier.  Numbers >= cnt_x mean "no tile left".
+    unsigned drawn = 0;
+    auto draw = [&]() {
+        if (wave == 0) {
+            const unsigned l = fresh_lane();
+            if (l == 0) {       // (the lane number doubles as the zero offset; the register that holds the addend takes the result)
+                unsigned d = 1u;
+                // (s_nop 4: the counter's address may have been reloaded from an SGPR spill lane by the v_readlane right in front of
+                // this block, and hipcc pads no hazard into inline assembly -- 5 wait states from a VALU write of an SGPR to a vector
+                // memory instruction that reads it; tools/check_asm_hazards.py checks the ISA for this)
+                asm volatile("s_nop 4\n\tglobal_atomic_add %0, %1, %0, %2 sc0" : "+v"(d) : "v"(l), "s"(tile_ctr) : "memory");
+                drawn = d;
+            }
+        }
+    };
+    auto publish = [&](int slot) {
+        if (wave == 0) {
+            if (fresh_lane() == 0) mail[slot] = nwg_x + (int)drawn;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+    };
+
+    // ---- prologue: table + bias stash of the first tile, its first D stages in flight, stage 0 landed and visible; the second tile's number
+    int j_cur = (int)blockIdx.x >> 3;
+    draw();
     int co0_cur, ks_cur;
     unsigned px0_cur;
-    tile_of(0, co0_cur, px0_cur, ks_cur);
+    tile_of(j_cur, co0_cur, px0_cur, ks_cur);
     build_table(0, px0_cur);
     const bool has_bias = p.epilogue == YOLO_EPI_BIAS || p.epilogue == YOLO_EPI_BIAS_LRELU || p.epilogue == YOLO_EPI_BIAS_ADD_LRELU;
     auto load_stash = [&](int co0) {
@@ -317,9 +356,11 @@ __global__ void __launch_bounds__(512, 2) igemm_persist_kernel(const IgemmParams
     stage_reset(co0_cur, ks_cur);
 #pragma unroll
     for (int s0 = 0; s0 < D; ++s0) stage(s0);
-    wait_vmcnt<(D - 1) * LOADS>();
+    wait_vmcnt<(D - 1) * LOADS>();        // stage 0 has landed -- and the draw, which is older than every stage load, has returned
+    publish(0);
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
+    int j_next = __builtin_amdgcn_readfirstlane(mail[0]);
     PSTAMP(1);
 
     auto run = [&](auto ntc) {
@@ -566,14 +607,20 @@ __global__ void __launch_bounds__(512, 2) igemm_persist_kernel(const IgemmParams
         // spilling the accumulators around it): behind the workgroup's last tile the three boundary steps stage that tile's own first
         // stages once more -- 96 KB nobody reads; the kernel drains them before it ends.
         int nst = 0;                                        // stores of the previous epilogue, in channel tiles (0: none yet)
-        for (int ti = 0; ti < n_mine; ++ti) {
-            const int tn = ti + 1 < n_mine ? ti + 1 : ti;
+        // (a loop on a limit that the body lowers, not `do .. while (has_next)`: with the uncounted form hipcc keeps ~40 more registers
+        // live across the K loop and spills)
+        bool has_next;
+        int n_lim = cnt_x;
+        for (int ti = 0; ti < n_lim;) {
+            has_next = (unsigned)j_next < (unsigned)cnt_x;
             int co0_next, ks_next;
             unsigned px0_next;
-            tile_of(tn, co0_next, px0_next, ks_next);
+            tile_of(has_next ? j_next : j_cur, co0_next, px0_next, ks_next);
             step_x(ZeroC{}, nst, rbuf, lbuf, a0, b0, a1, b1);        // step 0
             adv();
-            // every wave is past the previous tile's epilogue (barrier of step 0): its table buffer is free for tile ti + 1
+            // every wave is past the previous tile's epilogue (barrier of step 0): its table buffer is free for the next tile;
+            // and the tile after that is requested from the queue now -- its number is needed a whole tile from here
+            draw();
             build_table((ti + 1) & 1, px0_next);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the table is in LDS before this wave arrives at the next barrier
             step_x(AccC{}, nst, rbuf, lbuf, a1, b1, a0, b0);         // step 1
@@ -586,6 +633,7 @@ __global__ void __launch_bounds__(512, 2) igemm_persist_kernel(const IgemmParams
             }
             step(rbuf, lbuf, a0, b0, a1, b1);               // step nk-4: stages the tile's last stage
             adv();
+            publish((ti + 1) & 1);                          // (the draw of step 0 is covered by the waits of steps 1 .. nk-4)
             // the next tile's first D stages ride under this tile's last D steps
             load_b_voff((ti + 1) & 1);
             stage_reset(co0_next, ks_next);
@@ -598,7 +646,7 @@ __global__ void __launch_bounds__(512, 2) igemm_persist_kernel(const IgemmParams
 #ifdef IGEMM_STAMPS
             if (ti == 0) PSTAMP(2);
             if (ti == 1) PSTAMP(4);
-            if (ti == n_mine - 1) PSTAMP(6);
+            if (!has_next) PSTAMP(6);
 #endif
             // channel tiles (of 16) this wave holds inside Cout: 4 but for a ragged last tile (Cout % 16 == 0, host-checked)
             nst = __builtin_amdgcn_readfirstlane(min(MT, max(0, (p.Cout - co0_cur - wco * WCH) >> 4)));
@@ -609,11 +657,25 @@ __global__ void __launch_bounds__(512, 2) igemm_persist_kernel(const IgemmParams
             if (ti == 1) PSTAMP(5);
 #endif
             // fragments of the next tile's step 0: its stage landed (wait of step nk-1) and is visible (barrier of step nk-1)
+            // (behind the last tile: of the restaged tile, unused)
             rd(rbuf == 0 ? NST - 1 : rbuf - 1, a0, b0);
             if (co0_next != co0_cur) load_stash(co0_next);  // (the same wave writes and reads its stash: in order)
             co0_cur = co0_next;
+            j_cur = j_next;
+            j_next = __builtin_amdgcn_readfirstlane(mail[(ti + 1) & 1]);     // published in front of the barrier of step nk-3
+            ++ti;
+            if (!has_next) n_lim = ti;
         }
-        wait_vmcnt<0>();                                    // no LDS-DMA may outlive the workgroup
+        wait_vmcnt<0>();                                    // no LDS-DMA may outlive the workgroup (and the last draw has returned)
+        // the label's last workgroup to leave puts both counters back to zero for the next launch that uses this slot: nobody of the
+        // label draws any more (every workgroup's draws have returned before it counts itself out)
+        if (threadIdx.x == 0) {
+            const unsigned gone = atomicAdd(p.tile_ctr + 8 + xl, 1u);
+            if (gone == (unsigned)nwg_x - 1u) {
+                atomicExch(p.tile_ctr + xl, 0u);
+                atomicExch(p.tile_ctr + 8 + xl, 0u);
+            }
+        }
     };
     if (grp == 0) run(std::integral_constant<int, NT0>{});
     else run(std::integral_constant<int, NT1>{});
@@ -636,6 +698,28 @@ static void magic_u31(unsigned d, unsigned &magic, unsigned &shift)
     const unsigned long long num = 1ull << (31 + l);
     magic = (unsigned)((num + d - 1) / d);
     shift = l - 1;
+}
+
+// Tile counters: a ring of slots (16 words each: 8 draw counters + 8 leave counters, one pair per XCD label), one slot per launch so that
+// launches on different streams never share counters; a slot is zero again when its kernel has finished (the kernel resets it), and comes
+// round after RING launches.  Allocated and cleared once per device.
+static unsigned *persist_counters(int dev)
+{
+    constexpr unsigned RING = 1024;
+    static unsigned *ring[64] = {};
+    static std::atomic<unsigned> next[64];
+    static std::mutex mu;
+    if (!ring[dev]) {
+        std::lock_guard<std::mutex> g(mu);
+        if (!ring[dev]) {
+            unsigned *r = nullptr;
+            if (hipMalloc(&r, RING * 16 * sizeof(unsigned)) != hipSuccess) return nullptr;
+            // (hipMemset on device memory may return before it has run, and the launch streams do not wait for the null stream)
+            if (hipMemset(r, 0, RING * 16 * sizeof(unsigned)) != hipSuccess || hipDeviceSynchronize() != hipSuccess) return nullptr;
+            ring[dev] = r;
+        }
+    }
+    return ring[dev] + 16u * (next[dev].fetch_add(1u, std::memory_order_relaxed) % RING);
 }
 
 template <int NTILES, bool POOL, int DGRAD, bool CODES = false, bool SLAB = false, int MT = 4>
@@ -668,6 +752,8 @@ static int persist_launch(const IgemmParams &p, int splits, hipStream_t s)
     const long tiles = (long)q.n_co_tiles * q.n_px_tiles * (SLAB ? splits : 1);
     const int G = (int)std::min<long>(tiles, cus[dev]);
     q.pool_tiles_x = SLAB ? splits : 1;
+    q.tile_ctr = persist_counters(dev);
+    if (!q.tile_ctr) return fail(2, "yolo_igemm: cannot allocate the tile counters");
     hipLaunchKernelGGL((igemm_persist_kernel<NTILES, POOL, DGRAD, CODES, SLAB, MT>), dim3(G), dim3(C::NTHR), C::LDS_BYTES, s, q);
     return check_launch("yolo_igemm (persistent)");
 }
