@@ -311,7 +311,7 @@ def test_wgrad_kernel_variants_agree_bit_for_bit(Cin):
     x.interior().copy_(torch.randn(N, H, W, Cin, device="cuda").to(torch.bfloat16))
     dy.interior().copy_((torch.randn(N, H, W, Cout, device="cuda") * 0.1).to(torch.bfloat16))
     outs = []
-    for variant in (1, 2, 3, 4, 5):          # 5: 256 x 256 tile, register-pipelined loop (wgrad_pipe.hip)
+    for variant in (1, 2, 3, 4, 5, 6):       # 5: 256 x 256 tile, register-pipelined loop (wgrad_pipe.hip); 6: four waves of 128 x 128 (wgrad_wide.hip)
         dw = torch.full((Cout, 3, 3, Cin), float("nan"), device="cuda")
         db = torch.zeros(Cout, device="cuda")
         wd = WgradDesc(dy.slots, dy.px_stride, x.px_stride, Cout, Cin, 3, 3, 1, x.row_stride, 1, 0, variant)
@@ -322,33 +322,39 @@ def test_wgrad_kernel_variants_agree_bit_for_bit(Cin):
     torch.testing.assert_close(outs[0][0], ref, rtol=2e-3, atol=2e-3)
     for dw, db in outs[1:]:
         assert torch.equal(dw, outs[0][0]) and torch.equal(db, outs[0][1])
-    # the pipelined kernel in pixel-geometry mode (interior pixels only) and with the library's two-segment schedule (atomics)
-    for split in (1, 0):
-        dw = torch.zeros((Cout, 3, 3, Cin), device="cuda")
-        db = torch.zeros(Cout, device="cuda")
-        wd = WgradDesc(N * H * W, dy.px_stride, x.px_stride, Cout, Cin, 3, 3, 1, x.row_stride, split, 0, 5, W, H, dy.Hp * dy.Wp, dy.Wp, 1, dy.halo * dy.Wp + dy.halo)
-        check(lib().yolo_wgrad(ctypes.byref(wd), x.p, dy.p, ptr(dw), ptr(db), stream()))
-        torch.testing.assert_close(dw, outs[0][0], rtol=1e-4, atol=1e-4)
-        torch.testing.assert_close(db, outs[0][1], rtol=1e-4, atol=1e-4)
-    # slab mode: partial tiles stored + summed in pixel-range order -- no zero fill needed, bit-reproducible, equal to the atomics' result
-    # up to the order of the sum; uniform split (3 ranges) and the library's two-segment schedule
-    for split in (3, 0):
-        wd = WgradDesc(N * H * W, dy.px_stride, x.px_stride, Cout, Cin, 3, 3, 1, x.row_stride, split, 0, 5, W, H, dy.Hp * dy.Wp, dy.Wp, 1, dy.halo * dy.Wp + dy.halo)
-        need = ctypes.c_long(0)
-        check(lib().yolo_wgrad_slab_floats(ctypes.byref(wd), ctypes.byref(need)))
-        assert need.value > 0 and need.value % (256 * 256) == 0
-        slabs = torch.full((need.value,), float("nan"), device="cuda")
-        wd.slabs, wd.slab_floats = slabs.data_ptr(), slabs.numel()
-        runs = []
-        for _ in range(2):
-            dw = torch.full((Cout, 3, 3, Cin), float("nan"), device="cuda")
+    # the pipelined kernels in pixel-geometry mode (interior pixels only) and with the library's two-segment schedule (atomics)
+    for variant in (5, 6):
+        for split in (1, 0):
+            dw = torch.zeros((Cout, 3, 3, Cin), device="cuda")
             db = torch.zeros(Cout, device="cuda")
+            wd = WgradDesc(N * H * W, dy.px_stride, x.px_stride, Cout, Cin, 3, 3, 1, x.row_stride, split, 0, variant, W, H, dy.Hp * dy.Wp, dy.Wp, 1, dy.halo * dy.Wp + dy.halo)
             check(lib().yolo_wgrad(ctypes.byref(wd), x.p, dy.p, ptr(dw), ptr(db), stream()))
-            runs.append(dw)
-        torch.testing.assert_close(runs[0], outs[0][0], rtol=1e-4, atol=1e-4)
-        assert torch.equal(runs[0], runs[1])
-        wd.slab_floats = need.value - 1
-        assert lib().yolo_wgrad(ctypes.byref(wd), x.p, dy.p, ptr(dw), ptr(db), stream()) != 0      # scratch too small: refused
+            torch.testing.assert_close(dw, outs[0][0], rtol=1e-4, atol=1e-4)
+            torch.testing.assert_close(db, outs[0][1], rtol=1e-4, atol=1e-4)
+    # slab mode: partial tiles stored + summed in pixel-range order -- no zero fill needed, bit-reproducible, equal to the atomics' result
+    # up to the order of the sum; uniform split (3 ranges) and the library's two-segment schedule; both kernels produce the same partial tiles
+    slab_runs = {}
+    for variant in (5, 6):
+        for split in (3, 0):
+            wd = WgradDesc(N * H * W, dy.px_stride, x.px_stride, Cout, Cin, 3, 3, 1, x.row_stride, split, 0, variant, W, H, dy.Hp * dy.Wp, dy.Wp, 1, dy.halo * dy.Wp + dy.halo)
+            need = ctypes.c_long(0)
+            check(lib().yolo_wgrad_slab_floats(ctypes.byref(wd), ctypes.byref(need)))
+            assert need.value > 0 and need.value % (256 * 256) == 0
+            slabs = torch.full((need.value,), float("nan"), device="cuda")
+            wd.slabs, wd.slab_floats = slabs.data_ptr(), slabs.numel()
+            runs = []
+            for _ in range(2):
+                dw = torch.full((Cout, 3, 3, Cin), float("nan"), device="cuda")
+                db = torch.zeros(Cout, device="cuda")
+                check(lib().yolo_wgrad(ctypes.byref(wd), x.p, dy.p, ptr(dw), ptr(db), stream()))
+                runs.append(dw)
+            torch.testing.assert_close(runs[0], outs[0][0], rtol=1e-4, atol=1e-4)
+            assert torch.equal(runs[0], runs[1])
+            slab_runs[(variant, split)] = runs[0]
+            wd.slab_floats = need.value - 1
+            assert lib().yolo_wgrad(ctypes.byref(wd), x.p, dy.p, ptr(dw), ptr(db), stream()) != 0      # scratch too small: refused
+    for split in (3, 0):
+        assert torch.equal(slab_runs[(5, split)], slab_runs[(6, split)])
 
 
 def test_stride2_data_gradient_by_parity_classes():

@@ -1149,12 +1149,13 @@ static int wgrad_run(const yolo_wgrad_desc *d, const void *x, const void *dy, fl
         p.n_ci_tiles = (d->Cin + WG_T - 1) / WG_T;
         p.ntaps = d->KH * d->KW;
         // Cin == 64 with several taps (the 64 -> 192 3x3 layer): two taps per 128-column tile instead of half-empty tiles
-        p.pair_taps = ((d->variant <= 1 || d->variant == 4) && d->variant != 5 && d->Cin == 64 && p.ntaps > 1 && d->x_px_stride >= 64) ? 1 : 0;
+        p.pair_taps = ((d->variant <= 1 || d->variant == 4) && d->Cin == 64 && p.ntaps > 1 && d->x_px_stride >= 64) ? 1 : 0;
         const long steps_total = (d->P + WG_BP - 1) / WG_BP;
         // kernel variant: 256-wide co tiles (8 waves, 3 stages) only on request (d->variant == 2): measured no faster
         // than two co-resident 128 x 128 workgroups on any layer of the model
         const bool big = d->variant == 2 || d->variant == 3;   // 3: + staggered two-phase schedule
-        const bool pipe = d->variant == 5;                      // 256 x 256 tile, register-pipelined loop (wgrad_pipe.hip)
+        const bool pipe = d->variant == 5 || d->variant == 6;   // 256 x 256 tile, register-pipelined loop (wgrad_pipe.hip: eight waves of
+                                                                // 128 x 64; wgrad_wide.hip (6): four waves of 128 x 128)
         p.n_co_tiles = big ? (d->Cout + W2_TCO - 1) / W2_TCO : (d->Cout + WG_T - 1) / WG_T;
         int tiles = p.n_co_tiles * p.n_ci_tiles * (p.pair_taps ? (p.ntaps + 1) / 2 : p.ntaps);
         p.tile_taps = 1;
@@ -1241,7 +1242,7 @@ static int wgrad_run(const yolo_wgrad_desc *d, const void *x, const void *dy, fl
         if (d->dw_sumsq && (pipe || big || d->variant == 4 || p.atomic || (d->Cin & 3) || ((uintptr_t)dw & 15)))
             return fail(YOLO_E_UNSUPPORTED, "yolo_wgrad: dw_sumsq needs the 128 x 128 kernel storing every tile from one workgroup (split 1, no accumulate, Cin %% 4 == 0)");
         if (pipe) {
-            if (int rc = wgrad_pipe_launch(p, grid, s)) return rc;
+            if (int rc = d->variant == 6 ? wgrad_wide_launch(p, grid, s) : wgrad_pipe_launch(p, grid, s)) return rc;
             if (p.slabs) {
                 if (int rc = wgrad_slab_sum_launch(p, tiles, main_ranges, tail_ranges, s)) return rc;
             }

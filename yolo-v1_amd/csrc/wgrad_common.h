@@ -95,6 +95,8 @@ __device__ __forceinline__ void wgrad_map(const WgradParams &p, int nwg, int &bi
 
 // wgrad_pipe.hip: 256 x 256 tile, wave tile 128 x 64, register-pipelined one-barrier loop (yolo_wgrad_desc.variant = 5)
 int wgrad_pipe_launch(const WgradParams &p, dim3 grid, hipStream_t s);
+// wgrad_wide.hip: the same tiles and schedule, four waves of 128 x 128 with the accumulators in AGPRs (yolo_wgrad_desc.variant = 6)
+int wgrad_wide_launch(const WgradParams &p, dim3 grid, hipStream_t s);
 // ... slab mode: sum of the partial tiles into the packed gradient (main_ranges / tail_ranges = pixel ranges that hold pixels)
 int wgrad_slab_sum_launch(const WgradParams &p, int tiles, int main_ranges, int tail_ranges, hipStream_t s);
 // igemm.hip: the debug buffer of yolo_debug_stamps (diagnostic builds)

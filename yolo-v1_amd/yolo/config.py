@@ -38,7 +38,8 @@ class EngineConfig:
     SIDE_LOW: bool = True            # ... of the lowest scheduling priority: the dispatcher prefers the data-gradient chain (12.73 -> 12.55 ms per step)
     WGRAD_SLABS: bool = False        # pipelined weight-gradient kernel: partial tiles as slabs summed in fixed order instead of fp32 atomics (bit-reproducible,
                                      # 13-16 % faster per launch alone, slower inside the two-stream step: 12.06 -> 12.28 ms)
-    WGRAD_PIPE: bool = True          # weight gradient of the big deep 3x3 layers through wgrad_pipe.hip (yolo_wgrad_desc.variant = 5)
+    WGRAD_PIPE: bool = True          # weight gradient of the big deep 3x3 layers through the 256 x 256 pipelined kernels (yolo_wgrad_desc.variant = 5 / 6)
+    WGRAD_WIDE: bool = True          # ... variant 6 (wgrad_wide.hip: four waves of 128 x 128, accumulators in AGPRs) instead of 5, and on more layers
 
 
 CONFIG = EngineConfig()

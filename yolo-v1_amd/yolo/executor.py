@@ -630,9 +630,18 @@ class Plan:
         """yolo_wgrad problem of conv layer L over N images of the gradient buffer g / the input buffer xin"""
         # kernel variant: the 256 x 256 pipelined kernel (5) on the big deep layers, where the in-process A/B measured it 10-19 %
         # faster (56x56 256 -> 512, 28x28 512 -> 1024, 14x14 1024 -> 1024: tools/time_wgrad.py); the 128 x 128 kernel (0) elsewhere
-        deep = (L.Cout >= 512 and L.Cin >= 256 and N * L.Hout * L.Wout >= 40000) or (L.Cout >= 1024 and L.Cin >= 1024 and N * L.Hout * L.Wout >= 12000)
+        px = N * L.Hout * L.Wout
+        deep = (L.Cout >= 512 and L.Cin >= 256 and px >= 40000) or (L.Cout >= 1024 and L.Cin >= 1024 and px >= 12000)
         variant = 5 if (CFG.WGRAD_PIPE and L.K == 3 and L.stride == 1 and deep) else 0
-        if variant == 5 or (L.Hout >= 2 and L.Wout >= 2 and (L.stride > 1 or g.Hp * g.Wp >= 1.12 * L.Hout * L.Wout)):
+        flat = False
+        if CFG.WGRAD_PIPE and CFG.WGRAD_WIDE and L.K == 3 and L.stride == 1:
+            # variant 6 (tools/time_wgrad.py, each launch alone, same box): 56x56 256 -> 512 0.542 -> 0.484 ms, 28x28 512 -> 1024 0.499 -> 0.488,
+            # 112x112 64 -> 192 (four taps per 256-column tile) 0.360 (128 x 128 kernel) -> 0.303; NOT on 14x14 1024 -> 1024 (0.297 vs 0.287).
+            # From 56x56 up it reduces over every slot of the zero-haloed buffer (<= 7 % more pixels) and saves the pixel -> slot arithmetic.
+            if (deep and L.Cin < 1024) or (L.Cin == 64 and L.Cout >= 192 and px >= 500000):
+                variant = 6
+                flat = L.Hout >= 56 and L.Wout >= 56
+        if not flat and (variant >= 5 or (L.Hout >= 2 and L.Wout >= 2 and (L.stride > 1 or g.Hp * g.Wp >= 1.12 * L.Hout * L.Wout))):
             return WgradDesc(N * L.Hout * L.Wout, g.px_stride, xin.px_stride, L.Cout, L.Cin, L.K, L.K, L.pad, xin.row_stride, 0, 0, variant,
                              L.Wout, L.Hout, g.Hp * g.Wp, g.Wp * L.stride, L.stride, g.halo * g.Wp + g.halo)
         return WgradDesc(N * g.Hp * g.Wp, g.px_stride, xin.px_stride, L.Cout, L.Cin, L.K, L.K, L.pad, xin.row_stride, 0, 0, variant)
@@ -881,7 +890,7 @@ class Plan:
                         # (measured: worth it from 28x28 down and for stride 2; at 56x56 and above the halo is < 8 % of the slots
                         # and the per-row coordinate arithmetic costs more than it saves)
                         wd = self._wgrad_desc(L, g, xin, N)
-                        if self.c.WGRAD_SLABS and wd.variant == 5:
+                        if self.c.WGRAD_SLABS and wd.variant >= 5:
                             _attach_wgrad_slabs(L_, wd, dev)
                         with _timed(f"conv{li}.wgrad", "wgrad", 2.0 * N * L.Hout * L.Wout * L.Cout * L.Cin * L.K * L.K):
                             check(L_.yolo_wgrad(ctypes.byref(wd), xin.p, g.p, ptr(dwp), ptr(db), wst), f"wgrad conv{li}")
