@@ -89,7 +89,7 @@ def kernel_rooflines(fn, reps=2, alone=True):
         d[2] += 1
     how = "each launch timed alone -- one stream" if alone else "as scheduled: weight gradients on the second stream beside the data gradients, events on both streams"
     names = {"igemm": "igemm_persist_kernel / igemm_pipe_kernel / igemm_kernel / igemm_stream_kernel (implicit GEMM: conv / Linear forward and data gradient; " + how + ")",
-             "wgrad": "wgrad_kernel / wgrad_pipe_kernel (weight gradient, ds_read_b64_tr_b16 operands; " + how + ")", "stem": "stem_fwd_kernel (7x7/s2 stem)"}
+             "wgrad": "wgrad_kernel / wgrad_wide_kernel / wgrad_pipe_kernel (weight gradient, ds_read_b64_tr_b16 operands; " + how + ")", "stem": "stem_fwd_kernel (7x7/s2 stem)"}
     out = {}
     for kern, (ms, fl, n) in agg.items():
         if fl <= 0 or kern not in names:

@@ -14,7 +14,7 @@ LAST = int(sys.argv[2]) if len(sys.argv) > 2 and sys.argv[2].isdigit() else 0   
                                                          # found from bench's own launch count; everything earlier is warm-up / tuning
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
     rows = [(int(r["Dispatch_Id"]), float(r["Counter_Value"])) for r in csv.DictReader(open(f"{d}/pmc_{c}_counter_collection.csv"))
-            if (("wgrad_kernel" in r["Kernel_Name"] or "wgrad_pipe_kernel" in r["Kernel_Name"]) if WG else
+            if (("wgrad_kernel" in r["Kernel_Name"] or "wgrad_pipe_kernel" in r["Kernel_Name"] or "wgrad_wide_kernel" in r["Kernel_Name"]) if WG else
                 ("igemm_kernel" in r["Kernel_Name"] or "igemm_pipe_kernel" in r["Kernel_Name"] or "igemm_stream_kernel" in r["Kernel_Name"] or "igemm_persist_kernel" in r["Kernel_Name"]))
             and r["Counter_Name"] == c]
     rows.sort()
@@ -28,7 +28,7 @@ launches = n["FETCH_SIZE"]
 fetch = 2.0 * tot["FETCH_SIZE"] * 1024
 write = tot["WRITE_SIZE"] * 1024
 print(json.dumps({
-    "kernel": "wgrad_kernel + wgrad_pipe_kernel" if WG else "igemm_persist_kernel + igemm_pipe_kernel + igemm_kernel + igemm_stream_kernel", "launches_counted": launches,
+    "kernel": "wgrad_kernel + wgrad_pipe_kernel + wgrad_wide_kernel" if WG else "igemm_persist_kernel + igemm_pipe_kernel + igemm_kernel + igemm_stream_kernel", "launches_counted": launches,
     "hbm_read_bytes_per_launch": fetch / launches, "hbm_write_bytes_per_launch": write / launches,
     "hbm_bytes_per_launch": (fetch + write) / launches,
     "correction": "FETCH_SIZE x2 (gfx950 half-count of wide coalesced reads), KiB -> bytes; WRITE_SIZE exact",

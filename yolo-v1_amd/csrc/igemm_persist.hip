@@ -283,8 +283,16 @@ __global__ void __launch_bounds__(512, 2) igemm_persist_kernel(const IgemmParams
         for (int i = 0; i < C::A_PIECES; ++i)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(wb + (unsigned long)a_voff[i]),
                                              (__attribute__((address_space(3))) void *)(sb + i * NW * 1024), 16, 0, 0);
+#ifdef PERSIST_NO_B      // ablation build: what the K loop does without the pixel operand's LDS-DMA; wrong results
+        constexpr int NB = 0;
+        (void)xb;
+#elif defined(PERSIST_HALF_B)
+        const int NB = (kx == 1) ? C::B_PIECES : 0;          // ablation: the pixel operand staged for one tap column in three
+#else
+        constexpr int NB = C::B_PIECES;
+#endif
 #pragma unroll
-        for (int i = 0; i < C::B_PIECES; ++i)
+        for (int i = 0; i < NB; ++i)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(xb + (unsigned long)b_voff[i]),
                                              (__attribute__((address_space(3))) void *)(sb + A_BYTES + i * NW * 1024), 16, 0, 0);
         a_soff += BK * 2;
