@@ -464,7 +464,9 @@ int yolo_batchnorm_train_fwd(void *z_bf16, int N, int H, int W, int C, int halo,
                              float *scale_shift, void *out_bf16, int out_halo, float *save_mean_invstd,
                              int stats_ready, yolo_stream_t stream);
 /* (stats_ready = 1: acc2c already holds the sums -- the producing yolo_igemm accumulated them (yolo_igemm_desc.bn_stats) --
- *  and the statistics pass over z is skipped;
+ *  and the statistics pass over z is skipped; stats_ready = 2: z is normalised with running_mean / running_var as they are
+ *  (aten batch_norm(training=False): eval() mode of the reference's trunk, src/yolo/models.py:131-176, when gradients flow
+ *  through it); nothing is accumulated or updated, save_mean_invstd receives the running mean and 1/sqrt(running_var + eps);
  *  out_bf16 != NULL: the result goes to that buffer [N][H+2*out_halo][W+2*out_halo][C] and z is kept -- a trainable
  *  trunk needs z for the backward pass; save_mean_invstd != NULL: 4*C floats -- batch mean, 1/sqrt(var + eps), and the
  *  scale / shift the forward applied, y = fma(z, scale, shift).)
@@ -478,7 +480,8 @@ int yolo_batchnorm_train_fwd(void *z_bf16, int N, int H, int W, int C, int halo,
  *   dy' = dy * [y > 0];  dbeta = sum dy';  dgamma = sum dy' * xhat;  dz = gamma * invstd * (dy' - dbeta/M - xhat * dgamma/M)
  * dz is written at dz[n*dz_img_stride + y*dz_row_stride + x*dz_px_stride + dz_off + c] (doubled strides put it
  * zero-stuffed on the input grid of a stride-2 conv, the form yolo_wgrad / the data gradient read); store_masked_dy: dy'
- * replaces dy in place (the identity branch of a bottleneck receives it).  acc2c: as above (YOLO_BN_ACC_REPLICAS * 2*C
+ * replaces dy in place (the identity branch of a bottleneck receives it).  relu_from_z bit 1 (value 2 or 3): the forward ran
+ * with stats_ready = 2 (running statistics): dgamma / dbeta as above with the saved mean / invstd, dz = gamma * invstd * dy'.  acc2c: as above (YOLO_BN_ACC_REPLICAS * 2*C
  * doubles, zero on entry and on return); coef3c: 3*C floats of scratch. */
 int yolo_batchnorm_bwd(void *dy_bf16, int dy_halo, const void *y_bf16, int y_halo, const void *z_bf16, int z_halo,
                        int N, int H, int W, int C, const float *gamma, const float *mean_invstd, void *dz_bf16,

@@ -22,8 +22,9 @@ def _rel(a, b):
     return ((a - b).norm() / (b.norm() + 1e-20)).item()
 
 
-@pytest.mark.parametrize("relu,stride,from_z", [(True, 1, False), (False, 1, False), (True, 2, False), (True, 1, True)])
-def test_batchnorm_backward_matches_autograd(relu, stride, from_z):
+@pytest.mark.parametrize("relu,stride,from_z,frozen", [(True, 1, False, False), (False, 1, False, False), (True, 2, False, False), (True, 1, True, False),
+                                                        (True, 1, True, True), (False, 2, False, True)])
+def test_batchnorm_backward_matches_autograd(relu, stride, from_z, frozen):
     from yolo import engine
     from yolo._hip import lib, check, ptr, stream
     torch.manual_seed(0)
@@ -33,7 +34,11 @@ def test_batchnorm_backward_matches_autograd(relu, stride, from_z):
     gamma, beta = torch.rand(C) + 0.5, torch.randn(C)
     zc = z.clone().requires_grad_(True)
     gc, bc = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
-    yc = torch.nn.functional.batch_norm(zc, None, None, gc, bc, True, 0.1, 1e-5)
+    rm0, rv0 = torch.randn(C) * 0.4, torch.rand(C) + 0.5          # frozen: eval() mode, these ARE the statistics and stay as they are
+    if frozen:
+        yc = torch.nn.functional.batch_norm(zc, rm0, rv0, gc, bc, False, 0.1, 1e-5)
+    else:
+        yc = torch.nn.functional.batch_norm(zc, None, None, gc, bc, True, 0.1, 1e-5)
     if relu:
         yc = torch.relu(yc)
     yc.backward(dy)
@@ -47,18 +52,21 @@ def test_batchnorm_backward_matches_autograd(relu, stride, from_z):
     acc = torch.zeros(BN_ACC_REPLICAS * 2 * C, dtype=torch.float64, device=dev)
     ss = torch.empty(2 * C, dtype=torch.float32, device=dev)
     save = torch.empty(4 * C, dtype=torch.float32, device=dev)
-    rm, rv = torch.zeros(C, device=dev), torch.ones(C, device=dev)
+    rm, rv = (rm0.to(dev), rv0.to(dev)) if frozen else (torch.zeros(C, device=dev), torch.ones(C, device=dev))
     g_d, b_d = gamma.to(dev), beta.to(dev)
     check(lib().yolo_batchnorm_train_fwd(za.p, N, H, W, C, 1, ptr(g_d), ptr(b_d), 1e-5, 0.1, ptr(rm), ptr(rv), None, 0, 1 if relu else 0, ptr(acc), ptr(ss),
-                                         ya.p, 1, ptr(save), 0, st))
+                                         ya.p, 1, ptr(save), 2 if frozen else 0, st))
+    if frozen:
+        assert torch.equal(rm.cpu(), rm0) and torch.equal(rv.cpu(), rv0)
+        assert lib().yolo_batchnorm_train_fwd(za.p, N, H, W, C, 1, ptr(g_d), ptr(b_d), 1e-5, 0.1, None, None, None, 0, 1, ptr(acc), ptr(ss), ya.p, 1, ptr(save), 2, st) != 0
     assert torch.equal(za.interior().float().cpu(), z.permute(0, 2, 3, 1))                 # z kept
     assert _rel(ya.interior().permute(0, 3, 1, 2), yc) < 0.01
     dz = engine.Act(N, H * stride, W * stride, C, 1, dev)
     dgam, dbet = torch.empty(C, device=dev), torch.empty(C, device=dev)
     coef = torch.empty(3 * C, device=dev)
     check(lib().yolo_batchnorm_bwd(ga.p, 1, ya.p if (relu and not from_z) else None, 1, za.p, 1, N, H, W, C, ptr(g_d), ptr(save), dz.p, dz.img_stride,
-                                   stride * dz.row_stride, stride * dz.px_stride, dz.interior_off(), 1, 1 if from_z else 0, ptr(dgam), ptr(dbet), ptr(acc),
-                                   ptr(coef), st))
+                                   stride * dz.row_stride, stride * dz.px_stride, dz.interior_off(), 1, (1 if from_z else 0) | (2 if frozen else 0), ptr(dgam), ptr(dbet),
+                                   ptr(acc), ptr(coef), st))
     torch.cuda.synchronize()
     assert float(acc.abs().max()) == 0.0
     got = dz.interior()[:, ::stride, ::stride, :].permute(0, 3, 1, 2)
@@ -120,17 +128,32 @@ def _small_trunk():
     return t
 
 
-def test_trunk_backward_block_by_block():
+@pytest.mark.parametrize("mode,hw", [("train", (128, 128)), ("eval", (128, 128)), ("train", (104, 120))])
+def test_trunk_backward_block_by_block(mode, hw):
+    """hw (104, 120): a stem map of 52 x 60 that the direct 7x7 weight-gradient kernel's 8 x 16-pixel tiles do not cover (row-unfolded copy +
+    generic kernel instead), odd maps further down (13 x 15, 7 x 8).  mode "eval": gradients through the trunk in eval() mode -- every BatchNorm normalises with its running statistics
+    (batch_norm(training=False)), nothing is updated, the backward pass has no batch terms (reference: stock autograd through
+    src/yolo/models.py:131-176 in any mode)."""
     from yolo import engine
     trunk = _small_trunk()
-    gpu = copy.deepcopy(trunk).cuda().train()
+    if mode == "eval":
+        torch.manual_seed(5)
+        for m in trunk.modules():
+            if isinstance(m, nn.BatchNorm2d):
+                m.running_mean.uniform_(-0.3, 0.3)
+                m.running_var.uniform_(0.5, 1.5)
+    gpu = copy.deepcopy(trunk).cuda()
+    gpu = gpu.train() if mode == "train" else gpu.eval()
     plan = engine.ResNetPlan(gpu)
     plan.trace = []
     N = 8
-    x = torch.randn(N, 3, 128, 128)
+    x = torch.randn(N, 3, *hw)
     params = list(gpu.parameters())
-    out = engine.ResNetTrainFunction.apply(plan, x.cuda(), *params)
-    assert out.shape == (N, 2048, 4, 4)
+    out = engine.ResNetTrainFunction.apply(plan, mode == "eval", x.cuda(), *params)
+    assert out.shape == (N, 2048, 4, 4)            # both sizes end in a 4 x 4 map
+    if mode == "eval":
+        for (n, b), (_, b0) in zip(gpu.named_buffers(), trunk.named_buffers()):
+            assert torch.equal(b.cpu(), b0), n          # running statistics and num_batches_tracked untouched
     gout = torch.randn_like(out)
     saved_blocks = None
 
@@ -139,7 +162,8 @@ def test_trunk_backward_block_by_block():
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in params)
     tr = {(k, what): g for (k, what, g) in plan.trace}
     # blocks in forward order with the Acts that the plan still holds
-    cpu = copy.deepcopy(trunk).train()
+    cpu = copy.deepcopy(trunk)
+    cpu = cpu.train() if mode == "train" else cpu.eval()
     with torch.no_grad():
         for m in cpu.modules():
             if isinstance(m, nn.Conv2d):

@@ -104,19 +104,25 @@ __global__ void __launch_bounds__(256) bn_stats_kernel(const bf16_t *__restrict_
 
 __global__ void bn_finalize_kernel(double *__restrict__ acc, int C, double count, const float *__restrict__ gamma, const float *__restrict__ beta, double eps,
                                    double momentum, float *__restrict__ running_mean, float *__restrict__ running_var, float *__restrict__ scale,
-                                   float *__restrict__ shift, float *__restrict__ save_mean_invstd)
+                                   float *__restrict__ shift, float *__restrict__ save_mean_invstd, int frozen)
 {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
-    double s1 = 0.0, s2 = 0.0;
-    for (int r = 0; r < YOLO_BN_ACC_REPLICAS; ++r) {
-        s1 += acc[(size_t)r * 2 * C + c];
-        s2 += acc[(size_t)r * 2 * C + C + c];
-        acc[(size_t)r * 2 * C + c] = 0.0;          // ready for the next layer
-        acc[(size_t)r * 2 * C + C + c] = 0.0;
+    double mean, var;
+    if (frozen) {          // eval() mode with gradients: the running statistics ARE the statistics (aten batch_norm(training=False)); nothing is updated
+        mean = (double)running_mean[c];
+        var = (double)running_var[c];
+    } else {
+        double s1 = 0.0, s2 = 0.0;
+        for (int r = 0; r < YOLO_BN_ACC_REPLICAS; ++r) {
+            s1 += acc[(size_t)r * 2 * C + c];
+            s2 += acc[(size_t)r * 2 * C + C + c];
+            acc[(size_t)r * 2 * C + c] = 0.0;          // ready for the next layer
+            acc[(size_t)r * 2 * C + C + c] = 0.0;
+        }
+        mean = s1 / count;
+        var = s2 / count - mean * mean;
     }
-    const double mean = s1 / count;
-    double var = s2 / count - mean * mean;
     if (var < 0.0) var = 0.0;
     const double invstd = 1.0 / sqrt(var + eps);
     const double sc = (double)gamma[c] * invstd;
@@ -126,7 +132,7 @@ __global__ void bn_finalize_kernel(double *__restrict__ acc, int C, double count
         save_mean_invstd[c] = (float)mean; save_mean_invstd[C + c] = (float)invstd;
         save_mean_invstd[2 * C + c] = scale[c]; save_mean_invstd[3 * C + c] = shift[c];
     }
-    if (running_mean) {
+    if (running_mean && !frozen) {
         running_mean[c] = (float)((1.0 - momentum) * (double)running_mean[c] + momentum * mean);
         const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
         running_var[c] = (float)((1.0 - momentum) * (double)running_var[c] + momentum * unbiased);
@@ -240,7 +246,7 @@ __global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(const bf16_t *__rest
 }
 
 __global__ void bn_bwd_finalize_kernel(double *__restrict__ acc, int C, double count, const float *__restrict__ gamma, const float *__restrict__ mean_invstd,
-                                       float *__restrict__ dgamma, float *__restrict__ dbeta, float *__restrict__ coef)
+                                       float *__restrict__ dgamma, float *__restrict__ dbeta, float *__restrict__ coef, int frozen)
 {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
@@ -254,8 +260,9 @@ __global__ void bn_bwd_finalize_kernel(double *__restrict__ acc, int C, double c
     dbeta[c] = (float)s1;
     dgamma[c] = (float)s2;
     coef[c] = gamma[c] * mean_invstd[C + c];
-    coef[C + c] = (float)(s1 / count);
-    coef[2 * C + c] = (float)(s2 / count);
+    // frozen statistics (eval mode): mean and variance do not depend on z, so dz = gamma * invstd * dy' -- the two batch terms drop out
+    coef[C + c] = frozen ? 0.0f : (float)(s1 / count);
+    coef[2 * C + c] = frozen ? 0.0f : (float)(s2 / count);
 }
 
 __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(bf16_t *__restrict__ dy, int dy_halo, const bf16_t *__restrict__ yact, int y_halo,
@@ -308,6 +315,8 @@ YOLO_API int yolo_batchnorm_train_fwd(void *z, int N, int H, int W, int C, int h
         return fail(YOLO_E_ARG, "yolo_batchnorm_train_fwd: bad argument");
     if (C & 7) return fail(YOLO_E_UNSUPPORTED, "yolo_batchnorm_train_fwd: C = %d must be a multiple of 8", C);
     if ((running_mean == nullptr) != (running_var == nullptr)) return fail(YOLO_E_ARG, "yolo_batchnorm_train_fwd: running_mean and running_var go together");
+    if (stats_ready < 0 || stats_ready > 2 || (stats_ready == 2 && !running_mean))
+        return fail(YOLO_E_ARG, "yolo_batchnorm_train_fwd: stats_ready is 0, 1 or 2 (2 = normalise with the running statistics, which must be given)");
     hipStream_t s = STRM(stream);
     const int C8 = C / 8, gpb = C8 < 256 ? C8 : 256, ppb = 256 / gpb;
     const long P = (long)N * H * W;
@@ -319,7 +328,7 @@ YOLO_API int yolo_batchnorm_train_fwd(void *z, int N, int H, int W, int C, int h
         if (int rc = check_launch("yolo_batchnorm_train_fwd(stats)")) return rc;
     }
     hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, s, acc2c, C, (double)P, gamma, beta, eps, momentum, running_mean, running_var, scale_shift,
-                       scale_shift + C, save_mean_invstd);
+                       scale_shift + C, save_mean_invstd, stats_ready == 2 ? 1 : 0);
     if (int rc = check_launch("yolo_batchnorm_train_fwd(finalize)")) return rc;
     const long total = P * C8;
     hipLaunchKernelGGL(bn_apply_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (bf16_t *)z, N, H, W, C, halo, scale_shift, scale_shift + C,
@@ -331,6 +340,8 @@ YOLO_API int yolo_batchnorm_bwd(void *dy, int dy_halo, const void *y, int y_halo
                                 const float *mean_invstd, void *dz, long dz_img_stride, long dz_row_stride, long dz_px_stride, long dz_off, int store_masked_dy,
                                 int relu_from_z, float *dgamma, float *dbeta, double *acc2c, float *coef3c, yolo_stream_t stream)
 {
+    const int frozen = (relu_from_z >> 1) & 1;         // bit 1: the forward normalised with running statistics (stats_ready = 2)
+    relu_from_z &= 1;
     if (!dy || !z || !gamma || !mean_invstd || !dz || !dgamma || !dbeta || !acc2c || !coef3c || N <= 0 || H <= 0 || W <= 0 || C <= 0 || dy_halo < 0 || y_halo < 0 ||
         z_halo < 0 || (relu_from_z && y))
         return fail(YOLO_E_ARG, "yolo_batchnorm_bwd: bad argument (relu_from_z excludes y)");
@@ -345,7 +356,7 @@ YOLO_API int yolo_batchnorm_bwd(void *dy, int dy_halo, const void *y, int y_halo
     hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3((C8 + gpb - 1) / gpb, (unsigned)gy), dim3(256), 0, s, (const bf16_t *)dy, dy_halo, (const bf16_t *)y, y_halo,
                        (const bf16_t *)z, z_halo, N, H, W, C, mean_invstd, acc2c, relu_from_z);
     if (int rc = check_launch("yolo_batchnorm_bwd(reduce)")) return rc;
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, s, acc2c, C, (double)P, gamma, mean_invstd, dgamma, dbeta, coef3c);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, s, acc2c, C, (double)P, gamma, mean_invstd, dgamma, dbeta, coef3c, frozen);
     if (int rc = check_launch("yolo_batchnorm_bwd(finalize)")) return rc;
     const long total = P * C8;
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (bf16_t *)dy, dy_halo, (const bf16_t *)y, y_halo, (const bf16_t *)z,

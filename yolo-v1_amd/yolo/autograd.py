@@ -32,8 +32,8 @@ class ResNetTrainFunction(torch.autograd.Function):
     """autograd bridge of the trainable ResNet trunk: one node for the whole trunk (ResNetPlan.forward_train / backward_train)."""
 
     @staticmethod
-    def forward(ctx, plan, x: torch.Tensor, *params):
-        out, saved = plan.forward_train(x)
+    def forward(ctx, plan, frozen: bool, x: torch.Tensor, *params):
+        out, saved = plan.forward_train(x, frozen)
         ctx.plan, ctx.saved, ctx.params = plan, saved, params
         return out
 
@@ -44,7 +44,7 @@ class ResNetTrainFunction(torch.autograd.Function):
             raise RuntimeError("backward through a ResNet trunk forward that was already consumed")
         grads = ctx.plan.backward_train(ctx.saved, gout)
         ctx.saved = None
-        return (None, None) + tuple(grads.get(p) if p.requires_grad else None for p in ctx.params)
+        return (None, None, None) + tuple(grads.get(p) if p.requires_grad else None for p in ctx.params)
 
 
 @_hip.device_guard

@@ -102,7 +102,8 @@ class ResNetBackbone(Backbone):
     trunk is restated in ``yolo.resnet`` with torchvision's module names (``extractor.N...`` state_dict keys
     are the reference's).  ``pretrained=True`` needs the ImageNet weights, i.e. torchvision + a download.
     Device tensors run on the HIP engine: eval mode with BatchNorm folded and the residual add fused, training mode
-    (frozen backbone) with batch-statistics BatchNorm; a backward pass through the trunk is not built."""
+    (frozen backbone) with batch-statistics BatchNorm; a trainable trunk keeps every unit's conv output and runs the backward pass
+    on the device in both modes (batch statistics in train(), running statistics in eval())."""
 
     def __init__(self, pretrained: bool = True, freeze: bool = True):
         super().__init__()
@@ -127,11 +128,9 @@ class ResNetBackbone(Backbone):
             if self._plan is None:
                 self._plan = engine.ResNetPlan(self.extractor)
             if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-                if not self.training:
-                    raise NotImplementedError("gradients through a ResNetBackbone in eval() mode (running statistics) are not built: "
-                                              "train with model.train(), as the reference's trainer does, or freeze the backbone")
-                # trainable trunk in training mode -- the reference's default run (src/train.py:144)
-                return engine.ResNetTrainFunction.apply(self._plan, x, *self.extractor.parameters())
+                # trainable trunk: in training mode -- the reference's default run (src/train.py:144) -- BatchNorm normalises with batch
+                # statistics; in eval() mode with the running statistics as they are (stock autograd through batch_norm(training=False))
+                return engine.ResNetTrainFunction.apply(self._plan, not self.training, x, *self.extractor.parameters())
             if self.training:
                 # frozen but in training mode: BatchNorm uses batch statistics and updates its running statistics, exactly what
                 # the reference does (freeze does not put BN in eval; trainer.py:49 calls model.train() on everything)

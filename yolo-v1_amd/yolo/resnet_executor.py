@@ -104,8 +104,9 @@ class ResNetPlan:
         return out
 
     def _bn_train(self, a: Act, bn: nn.BatchNorm2d, relu: bool, residual: Act | None, dev, st, out: Act | None = None, save: torch.Tensor | None = None,
-                  stats_ready: bool = False):
-        """BatchNorm with batch statistics (+ residual, + ReLU) in place on the conv output, running statistics updated."""
+                  stats_ready: bool = False, frozen: bool = False):
+        """BatchNorm with batch statistics (+ residual, + ReLU) in place on the conv output, running statistics updated.
+        frozen: eval() mode with gradients -- normalise with the running statistics as they are, update nothing."""
         C = a.C
         acc, ss = self._scratch(dev)
         if C > 2048 or bn.weight is None or not bn.track_running_stats:
@@ -115,8 +116,9 @@ class ResNetPlan:
                                              ptr(bn.running_mean), ptr(bn.running_var), residual.p if residual is not None else None,
                                              residual.halo if residual is not None else 0, 1 if relu else 0, ptr(acc), ptr(ss),
                                              out.p if out is not None else None, out.halo if out is not None else 0,
-                                             ptr(save) if save is not None else None, 1 if stats_ready else 0, st), "batchnorm_train_fwd")
-        bn.num_batches_tracked += 1
+                                             ptr(save) if save is not None else None, 2 if frozen else (1 if stats_ready else 0), st), "batchnorm_train_fwd")
+        if not frozen:
+            bn.num_batches_tracked += 1
 
     def _scratch(self, dev):
         if self._bn_scratch is None or self._bn_scratch[0].device != dev:
@@ -225,8 +227,8 @@ class ResNetPlan:
         self._train_pk = (ver, out)
         return out
 
-    def _unit_fwd(self, tag, a_in: Act, packed, N, relu: bool, residual: Act | None, stats: torch.Tensor, dev, st):
-        """conv -> z (kept) -> BatchNorm(batch statistics) [+ residual] [ReLU] -> y; returns the record the backward needs."""
+    def _unit_fwd(self, tag, a_in: Act, packed, N, relu: bool, residual: Act | None, stats: torch.Tensor, dev, st, frozen: bool = False):
+        """conv -> z (kept) -> BatchNorm(batch statistics; frozen: running statistics) [+ residual] [ReLU] -> y; returns the record the backward needs."""
         wf, wd, conv, bn = packed
         k, s, p = conv.kernel_size[0], conv.stride[0], conv.padding[0]
         Ho, Wo = (a_in.H + 2 * p - k) // s + 1, (a_in.W + 2 * p - k) // s + 1
@@ -239,17 +241,20 @@ class ResNetPlan:
         d.stride, d.KH, d.KW, d.tap_len, d.Cout = s, k, k, conv.in_channels, conv.out_channels
         d.out_img_stride, d.out_row_stride, d.out_px_stride, d.out_off = z.img_stride, z.row_stride, z.px_stride, z.interior_off()
         d.epilogue, d.slope = EPI_NONE, 1.0
-        d.bn_stats = self._scratch(dev)[0].data_ptr() if CFG.BN_STATS_IN_CONV else None      # the conv's epilogue accumulates BatchNorm's sums
+        in_conv = CFG.BN_STATS_IN_CONV and not frozen
+        d.bn_stats = self._scratch(dev)[0].data_ptr() if in_conv else None      # the conv's epilogue accumulates BatchNorm's sums
         with _timed(str(tag), "igemm", 2.0 * N * Ho * Wo * conv.out_channels * conv.in_channels * k * k):
             igemm_call(d, a_in.p, ptr(wf), None, None, z.p, st, f"igemm {tag}")
-        self._bn_train(z, bn, relu, residual, dev, st, out=y, save=stats, stats_ready=CFG.BN_STATS_IN_CONV)
+        self._bn_train(z, bn, relu, residual, dev, st, out=y, save=stats, stats_ready=in_conv, frozen=frozen)
         return {"tag": tag, "conv": conv, "bn": bn, "x": a_in, "z": z, "y": y, "relu": relu, "res": residual is not None, "stats": stats, "wd": wd,
                 "k": k, "s": s, "p": p}
 
     @_hip.device_guard
-    def forward_train(self, x: torch.Tensor):
+    def forward_train(self, x: torch.Tensor, frozen: bool = False):
         """Training-mode forward of a TRAINABLE trunk (the reference's default run, src/train.py:144: ResNetBackbone(freeze=False)):
         as forward_batch_stats, but every unit keeps its conv output z, its activation y and the batch mean / invstd.
+        frozen: the trunk is in eval() mode and gradients are wanted -- every BatchNorm normalises with its running statistics
+        (aten batch_norm(training=False)) and updates nothing; the backward pass then has no batch terms.
         Returns (out, saved).  One forward may be in flight per plan (the buffers are reused step to step)."""
         _hip.require_cuda(x)
         st = RT.stream()
@@ -260,8 +265,6 @@ class ResNetPlan:
         if x.dtype != torch.float32 or not x.is_contiguous():
             x = x.float().contiguous()
         Ho, Wo = (H + 6 - 7) // 2 + 1, (W + 6 - 7) // 2 + 1
-        if Ho % 8 or Wo % 16:
-            raise NotImplementedError("trainable ResNet trunk: the stem's weight-gradient kernel needs an input of (16k) x (32k) pixels")
         nstat = 4 * (64 + sum(u.num_features for u in self.trunk.modules() if isinstance(u, nn.BatchNorm2d)))
         if getattr(self, "_stats", None) is None or self._stats.numel() < nstat or self._stats.device != dev:
             self._stats = torch.empty(nstat, dtype=torch.float32, device=dev)
@@ -285,7 +288,7 @@ class ResNetPlan:
         d.epilogue, d.slope = EPI_NONE, 1.0
         _igemm(RT.lib(), d, a.p, ptr(wf), None, None, z0.p, st, "igemm stem")
         stem = {"tag": "stem", "conv": conv, "bn": bn, "x": a, "z": z0, "y": y0, "relu": True, "res": False, "stats": stat(64)}
-        self._bn_train(z0, bn, True, None, dev, st, out=y0, save=stem["stats"])
+        self._bn_train(z0, bn, True, None, dev, st, out=y0, save=stem["stats"], frozen=frozen)
         Hq, Wq = (Ho - 1) // 2 + 1, (Wo - 1) // 2 + 1
         cur = self._act("pool", N, Hq, Wq, 64, 1, dev)
         pd = PoolDesc(N, Ho, Wo, 64, 1, 1)
@@ -296,17 +299,17 @@ class ResNetPlan:
                 ud = None
                 idn = cur
                 if blk.downsample is not None:
-                    ud = self._unit_fwd((li, bi, "d"), cur, pk[(li, bi, "d")], N, False, None, stat(blk.downsample[1].num_features), dev, st)
+                    ud = self._unit_fwd((li, bi, "d"), cur, pk[(li, bi, "d")], N, False, None, stat(blk.downsample[1].num_features), dev, st, frozen)
                     idn = ud["y"]
-                u1 = self._unit_fwd((li, bi, 1), cur, pk[(li, bi, 1)], N, True, None, stat(blk.bn1.num_features), dev, st)
-                u2 = self._unit_fwd((li, bi, 2), u1["y"], pk[(li, bi, 2)], N, True, None, stat(blk.bn2.num_features), dev, st)
-                u3 = self._unit_fwd((li, bi, 3), u2["y"], pk[(li, bi, 3)], N, True, idn, stat(blk.bn3.num_features), dev, st)
+                u1 = self._unit_fwd((li, bi, 1), cur, pk[(li, bi, 1)], N, True, None, stat(blk.bn1.num_features), dev, st, frozen)
+                u2 = self._unit_fwd((li, bi, 2), u1["y"], pk[(li, bi, 2)], N, True, None, stat(blk.bn2.num_features), dev, st, frozen)
+                u3 = self._unit_fwd((li, bi, 3), u2["y"], pk[(li, bi, 3)], N, True, idn, stat(blk.bn3.num_features), dev, st, frozen)
                 blocks.append((li, bi, u1, u2, u3, ud))
                 cur = u3["y"]
         out = torch.empty((N, cur.C, cur.H, cur.W), dtype=torch.float32, device=dev)
         check(RT.lib().yolo_nhwc_bf16_to_nchw_f32(cur.p, N, cur.C, cur.H, cur.W, cur.halo, ptr(out), st), "nhwc->nchw")
         self._train_gen = getattr(self, "_train_gen", 0) + 1
-        return out, {"N": N, "dev": dev, "stem": stem, "blocks": blocks, "out": cur, "gen": self._train_gen}
+        return out, {"N": N, "dev": dev, "stem": stem, "blocks": blocks, "out": cur, "gen": self._train_gen, "frozen": frozen}
 
     def backward_train(self, saved, gout: torch.Tensor) -> dict:
         """gradients of every trunk parameter for the forward recorded in `saved`: {parameter: fp32 gradient}."""
@@ -359,7 +362,8 @@ class ResNetPlan:
             from_z = u["relu"] and not u["res"]        # conv -> BN -> ReLU: the mask is recomputed from z, y is not read
             check(L_.yolo_batchnorm_bwd(dy.p, dy.halo, y.p if (u["relu"] and not from_z) else None, y.halo, z.p, z.halo, N, z.H, z.W, C,
                                         ptr(bn.weight.detach()), ptr(u["stats"]), dz.p, strides[0], strides[1], strides[2], strides[3],
-                                        1 if store_masked else 0, 1 if from_z else 0, ptr(dg), ptr(db), ptr(acc), ptr(self._coef), st),
+                                        1 if store_masked else 0, (1 if from_z else 0) | (2 if saved.get("frozen") else 0), ptr(dg), ptr(db), ptr(acc),
+                                        ptr(self._coef), st),
                   f"batchnorm_bwd {u['tag']}")
             grads[bn.weight], grads[bn.bias] = dg, db
             return dz
@@ -443,8 +447,18 @@ class ResNetPlan:
         if part is None or part.device != dev:
             part = self._stem_part = torch.empty((768 * 14400,), dtype=torch.float32, device=dev)
             self._stem_db = torch.empty(64, dtype=torch.float32, device=dev)
-        check(L_.yolo_wgrad_stem7(xin.p, dz0.p, N, y0.H, y0.W, xin.img_stride, xin.row_stride, dz0.img_stride, dz0.row_stride, dz0.interior_off(),
-                                  ptr(dw), ptr(self._stem_db), ptr(part), part.numel(), st), "wgrad_stem7")
+        if y0.H % 8 == 0 and y0.W % 16 == 0:
+            check(L_.yolo_wgrad_stem7(xin.p, dz0.p, N, y0.H, y0.W, xin.img_stride, xin.row_stride, dz0.img_stride, dz0.row_stride, dz0.interior_off(),
+                                      ptr(dw), ptr(self._stem_db), ptr(part), part.numel(), st), "wgrad_stem7")
+        else:
+            # stem maps that the direct kernel's 8 x 16-pixel tiles do not cover (inputs that are not (16k) x (32k) pixels): the generic weight-gradient
+            # kernel over a row-unfolded copy of the input (7 kernel rows x 8 columns x 4 channels per output pixel), as Plan.backward does
+            xcol = self._act(("stem", "xcol"), N, y0.H, y0.W, 7 * 32, 1, dev)
+            check(L_.yolo_im2col_rows(xin.p, xin.img_stride, xin.row_stride, xin.px_stride, 2, 7, 32, N, y0.H, y0.W, 1, xcol.p, st), "im2col_rows")
+            dwp = torch.zeros(64 * 7 * 8 * 4, dtype=torch.float32, device=dev)
+            wd = WgradDesc(dz0.slots, dz0.px_stride, xcol.px_stride, 64, 7 * 32, 1, 1, 0, xcol.row_stride, max(1, min(1024, dz0.slots // 4096)), 0)
+            check(L_.yolo_wgrad(ctypes.byref(wd), xcol.p, dz0.p, ptr(dwp), None, st), "wgrad stem")
+            check(L_.yolo_unpack_conv_wgrad(ptr(dwp), 64, 3, 7, 7, 4, 8, ptr(dw), 0, st), "unpack stem")
         grads[conv.weight] = dw
         if side_t is not None:
             main_t.wait_stream(side_t)          # every weight gradient is final before the pass returns
