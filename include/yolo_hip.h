@@ -233,8 +233,9 @@ typedef struct yolo_wgrad_desc {
     int32_t variant;                 /* 0: choose; 1: 128x128 tile, 4 waves, 2 stages; 2: 256x128 tile, 8 waves, 3 stages;
                                         3: 2 + staggered two-phase schedule; 4: 128x128 tile, 8 waves; 5: 256x256 tile, wave
                                         tile 128x64, four 32-pixel stages, register-pipelined one-barrier loop
-                                        (wgrad_pipe.hip; Cin in {64, 128}: 256 / Cin taps per tile)  (tests / tuning;
-                                        all agree bit for bit with one pixel range per tile)        */
+                                        (wgrad_pipe.hip; Cin in {64, 128}: 256 / Cin taps per tile); 6: the tiles and schedule of
+                                        5 with FOUR waves of 128x128, one per SIMD, 256 accumulator registers in AGPRs
+                                        (wgrad_wide.hip)  (tests / tuning; all agree bit for bit with one pixel range per tile)  */
     /* Pixel geometry (geo_W == 0: "flat" indexing, p IS the slot).  Otherwise the reduction runs over the P = N*geo_H*geo_W
      * pixels p = (n*geo_H + oy)*geo_W + ox only, and pixel p lives in slot
      *     n*geo_img_slots + oy*geo_row_slots + ox*geo_px_slots + geo_slot0
@@ -246,7 +247,7 @@ typedef struct yolo_wgrad_desc {
                                         global gradient norm of clip_grad_norm_ (trainer.py:79) then needs no pass over the 822 MB
                                         gradient of the Linear behind nn.Flatten.  Only with every tile stored by one workgroup
                                         (split = 1, accumulate = 0, variant 0 / 1, Cin % 4 == 0); otherwise YOLO_E_UNSUPPORTED */
-    float *slabs;                    /* optional (variant 5, accumulate = 0, Cin % 4 == 0): scratch of slab_floats floats.  Every workgroup then
+    float *slabs;                    /* optional (variant 5 / 6, accumulate = 0, Cin % 4 == 0): scratch of slab_floats floats.  Every workgroup then
                                         STORES its 256 x 256 partial tile there and a second kernel adds the partials of a tile in pixel-range
                                         order into dw -- no fp32 atomics on dw (1.5 TB/s chip-wide, 60-90 k cycles per workgroup), dw need not
                                         be zero-filled, and dw is bit-reproducible.  yolo_wgrad_slab_floats gives the size a launch needs */
