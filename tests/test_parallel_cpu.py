@@ -408,9 +408,9 @@ def test_plan_backward_buckets_are_reduced_from_a_stream_that_has_their_gradient
         out, saved = plan.forward(x, True, False)
         rec.events.clear()
         plan.backward(saved, torch.zeros_like(out), False)
-        # the schedule as shipped: FC gradients on the main stream, conv weight gradients on the side stream
+        # the schedule as shipped: every weight gradient (conv and Linear) on the side stream; FC1's data gradient -- a yolo_wgrad launch too -- on main
         wg = [(e[1], e[2]) for e in rec.events if e[0] == "launch" and e[1].startswith("yolo_wgrad")]
-        assert sum(1 for n, s in wg if s == 0x2000) == 24 and sum(1 for n, s in wg if s == 0x1000) == 3      # (FC1's data gradient is a yolo_wgrad launch too)
+        assert sum(1 for n, s in wg if s == 0x2000) == 26 and sum(1 for n, s in wg if s == 0x1000) == 1
         assert ("wait", 0x1000, 0x2000) in rec.events                                # the join in front of on_backward_done
         assert len(red.log) >= 4
         covered = 0
@@ -421,7 +421,7 @@ def test_plan_backward_buckets_are_reduced_from_a_stream_that_has_their_gradient
                 assert s == cur or red._waits.get((cur, s), -1) >= t
         assert covered == plan.arena.numel()
         first = red.log[0]
-        assert first[2] == 0x1000 and all(p[2] == 0x1000 for p in first[3])          # FC2 + FC1 (822 MB) leave from the main stream
+        assert first[2] == 0x2000 and all(p[2] == 0x2000 for p in first[3])          # FC2 + FC1 (822 MB) leave from the stream that produced them
         assert any(cur == 0x2000 for _, _, cur, _ in red.log[1:-1])                  # conv buckets leave from the side stream
         assert red.log[-1][2] == 0x1000                                             # the tail (+ bias region) after the join, from main
         red.finish()

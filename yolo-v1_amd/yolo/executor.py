@@ -717,6 +717,7 @@ class Plan:
 
         with _on_side():
             scratch.zero_()
+        fc_keep: list = []
 
         # what each layer's input activation is
         def input_of(li):
@@ -761,13 +762,22 @@ class Plan:
                     # need not read the 822 MB of the Linear behind nn.Flatten again (yolo.optim.grad_norm_sq, `known`)
                     nsq = torch.zeros((), dtype=torch.float64, device=dev)
                     wd.dw_sumsq = nsq.data_ptr()
-                with _timed(f"fc{li}.wgrad", "wgrad", 2.0 * N * L.Cout * L.Cin):
-                    check(L_.yolo_wgrad(ctypes.byref(wd), ptr(xin), ptr(gb), ptr(dw), ptr(db), st), f"wgrad fc{li}")
+                if self.c.FC_WGRAD_SIDE and side_t is not None:
+                    # HBM-bound both: the weight gradient of the Linear behind nn.Flatten STORES 822 MB (4.1 TB/s alone), its data gradient READS
+                    # the 411 MB of weights (2.7 TB/s alone); side by side they share the memory system instead of taking turns
+                    fc_keep.append(gb)          # (a temporary of the main stream's allocator that the second stream reads: alive until the streams join)
+                    with _on_side() as wst:
+                        with _timed(f"fc{li}.wgrad", "wgrad", 2.0 * N * L.Cout * L.Cin):
+                            check(L_.yolo_wgrad(ctypes.byref(wd), ptr(xin), ptr(gb), ptr(dw), ptr(db), wst), f"wgrad fc{li}")
+                        self._layer_done(li)
+                else:
+                    with _timed(f"fc{li}.wgrad", "wgrad", 2.0 * N * L.Cout * L.Cin):
+                        check(L_.yolo_wgrad(ctypes.byref(wd), ptr(xin), ptr(gb), ptr(dw), ptr(db), st), f"wgrad fc{li}")
+                    self._layer_done(li)
                 if nsq is not None:
                     # (no reference to dw itself: autograd takes the gradient over without a copy only while nobody else holds it)
                     self.grad_norm_sq[id(L.weight)] = ((dw.data_ptr(), tuple(dw.shape)), dw._version, nsq)
                 grads[li] = (dw, db)
-                self._layer_done(li)
                 # data gradient
                 need_prev = li > 0 or need_gx
                 behind_flatten = li >= 2 and self.layers[li - 1].kind == "flatten" and self.layers[li - 2].kind in ("conv", "pool")
