@@ -748,3 +748,45 @@ def test_persistent_kernel_fuses_the_pool(W, H, cin, cout):
     assert torch.equal(got_c, ref_c), int((got_c != ref_c).sum())
     assert int((ref_c != -1).sum()) >= a_out.interior().numel() // 8 - 64   # the interior codes were written (0xffff is a legal code: a few), the rest was not
     assert int((ref_c != -1).sum()) <= a_out.interior().numel() // 8
+
+
+def test_persistent_kernels_draw_their_tiles_while_others_hold_the_chip():
+    """The tile queue of igemm_persist.hip: a workgroup's first tile is static, the others are drawn from per-XCD counters, so a launch
+    stays correct (and work-conserving) when its workgroups are NOT all resident at once.  Two persistent launches of different
+    problems run at the same time on two streams -- each needs a CU per workgroup (141 KB of LDS), so they take the chip from each
+    other in whatever order the dispatcher decides -- 40 times over; every output must equal the launch's result when it ran alone.
+    (Also crosses the 1024-slot counter ring's reuse: > 1100 persistent launches in this test.)"""
+    from yolo import engine
+    from yolo._hip import lib, ptr, stream
+    pa = _persist_problem(8, 64, 512, 3, 80, 96, "lrelu")          # 628 tiles: 2-3 per workgroup
+    pb = _persist_problem(8, 256, 512, 1, 80, 96, "gate")          # another kernel instantiation (data-gradient epilogue)
+    plan = ("tile", 20, 1, 196)
+
+    def launch(prob, st):
+        d, a_in, w, b, aux, a_out = prob
+        epi_bias = d.epilogue in (1, 2, 4)          # YOLO_EPI_BIAS, _BIAS_LRELU, _BIAS_ADD_LRELU
+        engine._run_plan_igemm(lib(), d, plan, a_in.p, ptr(w), ptr(b) if epi_bias else None, aux.p if d.epilogue in (3, 4) else None, a_out.p, st, "test")
+
+    refs = []
+    for prob in (pa, pb):
+        prob[5].t.fill_(7.0)
+        launch(prob, stream())
+        torch.cuda.synchronize()
+        refs.append(prob[5].interior().clone())
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    import ctypes
+    for rep in range(40):
+        pa[5].t.fill_(7.0)
+        pb[5].t.fill_(7.0)
+        torch.cuda.synchronize()
+        for k in range(7):                          # several launches deep on both streams: the two kernels keep meeting
+            launch(pa, ctypes.c_void_p(s1.cuda_stream))
+            launch(pb, ctypes.c_void_p(s2.cuda_stream))
+        torch.cuda.synchronize()
+        assert torch.equal(pa[5].interior(), refs[0]), rep
+        assert torch.equal(pb[5].interior(), refs[1]), rep
+    # 600 more single launches: every slot of the counter ring has been used and reset at least once
+    for k in range(600):
+        launch(pa, stream())
+    torch.cuda.synchronize()
+    assert torch.equal(pa[5].interior(), refs[0])
