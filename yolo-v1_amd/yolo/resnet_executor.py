@@ -9,11 +9,11 @@ import torch
 import torch.nn as nn
 
 from . import _hip
-from ._hip import (EPI_BIAS, EPI_BIAS_ADD_LRELU, EPI_BIAS_LRELU, EPI_MUL_DLRELU, EPI_NONE, ConvPackItem, ConvUnpackItem, IgemmDesc, PoolDesc, WgradDesc, check, ptr)
+from ._hip import (EPI_BIAS, EPI_BIAS_LRELU, EPI_NONE, ConvPackItem, ConvUnpackItem, IgemmDesc, PoolDesc, WgradDesc, check, ptr)
 from .config import CONFIG as CFG
 from .executor import Plan
 from .plans import igemm_call
-from .runtime import RT, Act, _attach_wgrad_slabs, _igemm, _on_side_stream, _round_up, _timed
+from .runtime import RT, Act, _igemm, _on_side_stream, _round_up, _timed
 
 # ====================================================================================================
 # ResNet-50 trunk, inference only (BatchNorm folded into the conv that precedes it)
