@@ -1,0 +1,32 @@
+#!/usr/bin/env python3
+"""A/B of two launch-plan tables on the batch-64 inference forward (YOLOv1, and the ResNet-50 variant with MODEL=resnet50) inside ONE process.
+usage: ab_plans.py TABLE_A.json TABLE_B.json [reps]"""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "yolo-v1_amd"))
+import torch
+from yolo import YOLOv1, ResNetBackbone, engine
+
+tables = sys.argv[1:3]
+reps = int(sys.argv[3]) if len(sys.argv) > 3 else 100
+resnet = os.environ.get("MODEL", "yolov1") == "resnet50"
+m = (YOLOv1(backbone=ResNetBackbone(pretrained=False, freeze=True)) if resnet else YOLOv1()).cuda().eval()
+x = torch.randn(64, 3, 448, 448, device="cuda")
+res = {t: [] for t in tables}
+with torch.no_grad():
+    for rnd in range(3):
+        for t in tables:
+            engine._TUNED.clear()
+            engine.load_plans(t)
+            if hasattr(m, "hip_plan") and not resnet:
+                m.hip_plan()._ws.clear()
+            for _ in range(10):
+                m(x)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                m(x)
+            torch.cuda.synchronize()
+            res[t].append(1e3 * (time.perf_counter() - t0) / reps)
+for t, v in res.items():
+    print(f"{os.path.basename(t)}: " + " ".join(f"{a:.4f}" for a in v) + f"  ms/forward (min {min(v):.4f})")

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""experiment: batch-64 inference forward replayed from a HIP graph vs launched eagerly (same process)"""
+"""experiment: inference forward (N=64 by default) replayed from a HIP graph vs launched eagerly (same process)"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "yolo-v1_amd"))
@@ -7,7 +7,7 @@ import torch
 from yolo import YOLOv1
 
 m = YOLOv1().cuda().eval()
-x = torch.randn(64, 3, 448, 448, device="cuda")
+x = torch.randn(int(os.environ.get("N", "64")), 3, 448, 448, device="cuda")
 with torch.no_grad():
     for _ in range(5):
         y0 = m(x)
