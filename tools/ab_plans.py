@@ -8,6 +8,9 @@ import torch
 from yolo import YOLOv1, ResNetBackbone, engine
 
 tables = sys.argv[1:3]
+for t in tables:
+    if not os.path.exists(t):
+        sys.exit(f"ab_plans: {t} does not exist (gpurun_out/ does not travel to the GPU box: keep tables to compare under build/)")
 reps = int(sys.argv[3]) if len(sys.argv) > 3 else 100
 resnet = os.environ.get("MODEL", "yolov1") == "resnet50"
 m = (YOLOv1(backbone=ResNetBackbone(pretrained=False, freeze=True)) if resnet else YOLOv1()).cuda().eval()

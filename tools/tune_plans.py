@@ -25,7 +25,9 @@ def main():
     ap.add_argument("--no-resnet", action="store_true")
     ap.add_argument("--out", default=engine.PLAN_FILE)
     ap.add_argument("--fresh", action="store_true")
+    ap.add_argument("--reps", type=int, default=1, help="launches per timed sample (1: one launch behind a cache flush; 8: back-to-back, warm caches)")
     a = ap.parse_args()
+    engine.TUNE_REPS = a.reps
     if a.fresh:
         engine._TUNED.clear()
     engine.AUTOTUNE = True

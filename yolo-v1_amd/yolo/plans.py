@@ -207,14 +207,17 @@ def _tune(L_, d: IgemmDesc, inp, w, bias, aux, out, st, what):
         except _hip.HipUnsupported:
             return None          # this configuration does not take the shape; every other error is a real failure
         ts = []
+        reps = CFG.TUNE_REPS
         for _ in range(3):
-            _flush_caches(dev)
+            if reps <= 1:
+                _flush_caches(dev)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            _run_plan_igemm(L_, d, plan, inp, w, bias, aux, out, st, what)
+            for _r in range(max(1, reps)):
+                _run_plan_igemm(L_, d, plan, inp, w, bias, aux, out, st, what)
             e1.record()
             e1.synchronize()
-            ts.append(e0.elapsed_time(e1))
+            ts.append(e0.elapsed_time(e1) / max(1, reps))
         return min(ts)
 
     times = {}
@@ -324,7 +327,15 @@ def igemm_call(d: IgemmDesc, inp, w, bias, aux, out, st, what: str):
         else:
             best = _default_plan(d)
         _TUNED[key] = best
+    rec = CFG.PLAN_TIMES
+    if rec is None:
+        _run_plan_igemm(L_, d, best, inp, w, bias, aux, out, st, what)
+        return
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
     _run_plan_igemm(L_, d, best, inp, w, bias, aux, out, st, what)
+    e1.record()
+    rec.setdefault(key, []).append((e0, e1))
 
 
 def _tune_key(d: IgemmDesc):
