@@ -39,6 +39,8 @@ class EngineConfig:
     WGRAD_SLABS: bool = False        # pipelined weight-gradient kernel: partial tiles as slabs summed in fixed order instead of fp32 atomics (bit-reproducible,
                                      # 13-16 % faster per launch alone, slower inside the two-stream step: 12.06 -> 12.28 ms)
     WGRAD_PIPE: bool = True          # weight gradient of the big deep 3x3 layers through the 256 x 256 pipelined kernels (yolo_wgrad_desc.variant = 5 / 6)
+    WGRAD_CHOICE: object = None      # dict {(N, Hout, Wout, Cout, Cin, K, stride): (variant, flat)}: overrides the shape rule of Plan._wgrad_desc (tools/search_wgrad.py; the
+                                     # shipped choices live in yolo/plans/gfx950.json under "wgrad")
     PLAN_TIMES: object = None        # dict: igemm_call records (start, end) events per problem key -- in-situ time of the plan in use (tools/merge_plans.py)
     TUNE_REPS: int = 1               # tuner: launches per timed sample (1: a single launch behind a cache flush; > 1: back-to-back launches, warm caches -- the regime inside a forward pass)
     FC_WGRAD_SIDE: bool = True       # the Linear layers' weight gradients on the second stream too: the 822 MB store of the big one runs beside the 411 MB read of its data gradient

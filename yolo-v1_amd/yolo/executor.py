@@ -641,7 +641,14 @@ class Plan:
             if (deep and L.Cin < 1024) or (L.Cin == 64 and L.Cout >= 192 and px >= 500000):
                 variant = 6
                 flat = L.Hout >= 56 and L.Wout >= 56
-        if not flat and (variant >= 5 or (L.Hout >= 2 and L.Wout >= 2 and (L.stride > 1 or g.Hp * g.Wp >= 1.12 * L.Hout * L.Wout))):
+        geo_ok = L.Hout >= 2 and L.Wout >= 2
+        geo = variant >= 5 or (geo_ok and (L.stride > 1 or g.Hp * g.Wp >= 1.12 * L.Hout * L.Wout))
+        choice = CFG.WGRAD_CHOICE.get((N, L.Hout, L.Wout, L.Cout, L.Cin, L.K, L.stride)) if CFG.WGRAD_CHOICE else None
+        if choice is not None and L.K == 3 and L.stride == 1 and CFG.WGRAD_PIPE and (int(choice[0]) != 6 or CFG.WGRAD_WIDE):
+            # a choice measured inside the training step (tools/search_wgrad.py): which kernel, and whether it walks every slot of the zero-haloed buffer
+            variant, flat = int(choice[0]), bool(choice[1])
+            geo = geo_ok and not flat
+        if not flat and geo:
             return WgradDesc(N * L.Hout * L.Wout, g.px_stride, xin.px_stride, L.Cout, L.Cin, L.K, L.K, L.pad, xin.row_stride, 0, 0, variant,
                              L.Wout, L.Hout, g.Hp * g.Wp, g.Wp * L.stride, L.stride, g.halo * g.Wp + g.halo)
         return WgradDesc(N * g.Hp * g.Wp, g.px_stride, xin.px_stride, L.Cout, L.Cin, L.K, L.K, L.pad, xin.row_stride, 0, 0, variant)

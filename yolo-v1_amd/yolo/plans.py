@@ -47,6 +47,9 @@ def load_plans(path: str = PLAN_FILE) -> int:
         data = json.load(f)
     for k, v in data.get("plans", {}).items():
         _TUNED[tuple(int(t) for t in k.split(","))] = tuple(v)
+    if data.get("wgrad"):           # weight-gradient kernel choices measured inside the training step (Plan._wgrad_desc)
+        CFG.WGRAD_CHOICE = dict(CFG.WGRAD_CHOICE or {})
+        CFG.WGRAD_CHOICE.update({tuple(int(t) for t in k.split(",")): tuple(int(t) for t in v) for k, v in data["wgrad"].items()})
     return len(data.get("plans", {}))
 
 
@@ -55,6 +58,8 @@ def save_plans(path: str = PLAN_FILE, note: str = "") -> None:
     os.makedirs(os.path.dirname(path), exist_ok=True)
     body = {"arch": "gfx950", "key": "N,Ho,Wo,KH,KW,tap_len,Cout,stride,epilogue,pool2,out_px_stride,in_px_stride", "note": note,
             "plans": {_key_str(k): list(v) for k, v in sorted(_TUNED.items())}}
+    if CFG.WGRAD_CHOICE:
+        body["wgrad"] = {_key_str(k): list(v) for k, v in sorted(CFG.WGRAD_CHOICE.items())}
     with open(path, "w") as f:
         json.dump(body, f, indent=0, separators=(",", ":"))
         f.write("\n")
