@@ -19,8 +19,11 @@ from . import _hip
 from ._hip import AdamTensor, check, lib, ptr, stream
 
 
-BG_CUS = 64        # CUs the background update of the Linear layers holds (yolo_adam_step_multi_bg): a CU streams ~42 GB/s whatever it keeps in flight,
-                   # so the pass runs at 2.6 TB/s there (2.4 ms) -- under the conv stack of the next forward; 24 CUs: too slow (step 13.9 ms), 96: same as 64
+BG_CUS = 128       # CUs the background update of the Linear layers holds (yolo_adam_step_multi_bg): a CU streams ~42 GB/s whatever it keeps in flight,
+                   # so the pass runs at ~4.5 TB/s there -- under the conv stack of the next forward, whose persistent kernels draw their tiles from a
+                   # queue and so lose only the share of the chip the pass holds.  Step at batch 64 (tools/ab_train.py, one process): 32 CUs 12.16 ms,
+                   # 48: 11.20, 64: 11.02-11.10, 96: 10.92, 128: 10.89-10.99, 160: 11.06, 192: 11.17, 256: 11.37.  (Round 2, statically scheduled conv
+                   # kernels: 64 was the optimum and 96 no better.)
 OVERLAP = os.environ.get("YOLO_ADAM_OVERLAP", "1") != "0"     # attach_plan(overlap=True) takes effect (switch for A/B runs)
 
 
