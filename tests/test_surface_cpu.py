@@ -390,3 +390,45 @@ def test_bench_launches_its_own_ranks(monkeypatch, capsys):
     cmd = seen["cmd"]
     assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node=8" in cmd and cmd[-4:] == ["--gpus", "8", "--steps", "3"]
     assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+
+
+def test_shipped_plan_table_and_weight_gradient_choices(tmp_path):
+    """yolo/plans/gfx950.json: every entry parses into a plan the engine knows, the "wgrad" section (kernel choices measured inside the
+    training step, tools/search_wgrad.py) reaches Plan._wgrad_desc, and save_plans / load_plans round-trip both sections."""
+    import json
+    from yolo import engine
+    from yolo import plans as P
+    from yolo.config import CONFIG
+    from yolo.executor import Layer, Plan
+    body = json.load(open(P.PLAN_FILE))
+    assert body["arch"] == "gfx950" and len(body["plans"]) >= 200
+    for k, v in body["plans"].items():
+        key = tuple(int(t) for t in k.split(","))
+        assert len(key) == 12 and key[0] in (1, 16, 64), k
+        assert isinstance(v[0], int) or v[0] in ("tile", "slabs", "splitk", "skew"), (k, v)
+    choice = CONFIG.WGRAD_CHOICE
+    assert choice and all(len(k) == 7 and v[0] in (0, 5, 6) and v[1] in (0, 1) for k, v in choice.items())
+    assert {",".join(map(str, k)): list(v) for k, v in choice.items()} == body["wgrad"]
+
+    class _A:      # the geometry fields of an activation buffer that _wgrad_desc reads
+        def __init__(self, H, W, C):
+            self.H, self.W, self.C, self.halo = H, W, C, 1
+            self.Hp, self.Wp = H + 2, W + 2
+            self.px_stride, self.row_stride = C, (W + 2) * C
+    (N, H, W, Cout, Cin, K, s), (variant, flat) = next(iter(choice.items()))
+    L = Layer.__new__(Layer)
+    L.Hout, L.Wout, L.Cout, L.Cin, L.K, L.stride, L.pad = H, W, Cout, Cin, K, s, 1
+    wd = Plan._wgrad_desc(L, _A(H, W, Cout), _A(H, W, Cin), N)
+    assert wd.variant == variant and (wd.geo_W == 0) == bool(flat)
+    old = CONFIG.WGRAD_CHOICE
+    try:
+        CONFIG.WGRAD_CHOICE = None
+        rule = Plan._wgrad_desc(L, _A(H, W, Cout), _A(H, W, Cin), N)
+        assert (rule.variant, rule.geo_W == 0) != (variant, bool(flat)), "an override that equals the shape rule says nothing"
+        CONFIG.WGRAD_CHOICE = old
+        out = tmp_path / "t.json"
+        P.save_plans(str(out), "round trip")
+        again = json.load(open(out))
+        assert again["plans"] == body["plans"] and again["wgrad"] == body["wgrad"]
+    finally:
+        CONFIG.WGRAD_CHOICE = old
