@@ -79,3 +79,17 @@ def test_binding_refuses_a_library_of_another_abi_version(monkeypatch, built):
     monkeypatch.setattr(_hip, "ABI_VERSION", 99)
     with pytest.raises(RuntimeError, match="ABI version"):
         _hip.lib()
+
+
+def test_inline_assembly_blocks_have_their_wait_states():
+    """hipcc pads data hazards only between instructions it emitted itself.  The kernels' hand-written vector-memory instructions take their
+    addresses from SGPRs that hipcc may reload from a spill lane (v_readlane) right in front of the asm block -- 5 wait states are needed and nobody
+    inserts them (a GPU fault in round 3 until the block carried its own s_nop).  tools/check_asm_hazards.py disassembles the kernels and checks
+    every asm block for this pattern; no GPU needed (hipcc cross-compiles)."""
+    import shutil
+    import sys
+    if not os.path.exists("/opt/rocm/bin/hipcc") and shutil.which("hipcc") is None:
+        pytest.skip("no hipcc")
+    files = [os.path.join(ROOT, "yolo-v1_amd", "csrc", f) for f in ("igemm_persist.hip", "wgrad_wide.hip", "wgrad_pipe.hip")]
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_asm_hazards.py")] + files, capture_output=True, text=True)
+    assert r.returncode == 0 and "inline-assembly hazards: 0" in r.stdout, r.stdout + r.stderr
