@@ -87,6 +87,7 @@ def test_inline_assembly_blocks_have_their_wait_states():
     inserts them (a GPU fault in round 3 until the block carried its own s_nop).  tools/check_asm_hazards.py disassembles the kernels and checks
     every asm block for this pattern; no GPU needed (hipcc cross-compiles)."""
     import shutil
+    import subprocess
     import sys
     if not os.path.exists("/opt/rocm/bin/hipcc") and shutil.which("hipcc") is None:
         pytest.skip("no hipcc")
