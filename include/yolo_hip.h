@@ -163,7 +163,11 @@ typedef struct yolo_igemm_desc {
                                atomics), 7-10: BK = 32 variants of 64x128, 19: streaming 1x1 convolution of the thin-K pointwise
                                layers (1x1, tap_len 64 / 128 / 192 / 256 / 512, Cout % 64 == 0, bf16 out, N*Ho*Wo % 16 == 0: the weight
                                panel sits in LDS, every wave walks 16-pixel groups with the next group's activation fragments and
-                               the residual vectors in flight; igemm_stream.hip)  (tuning / tests;
+                               the residual vectors in flight; igemm_stream.hip), 20 / 21: the persistent kernels (igemm_persist.hip: one software
+                               pipeline over all tiles of a workgroup, tiles of 256 x 208 / 224 drawn from per-XCD queues, epilogue out of the
+                               accumulator registers), 22: 3x3 / stride-1 conv of 64 -> 64 channels on maps of (16k) x (16k) pixels with the weight
+                               panel resident in LDS and the input patch of a 16 x 16 tile staged once (conv_c64.hip; epilogue NONE / BIAS /
+                               BIAS_LRELU, bf16 out, no pool2 / bn_stats / split_k)  (tuning / tests;
                                a caller that wants the best plan times them per problem, as engine.igemm_call does) */
     int64_t px_begin, px_end; /* compute only output pixels [px_begin, px_end) of the flattened (n, oy, ox) index
                                (0, 0 = all).  Lets a caller run the bulk of a layer with a large tile in whole

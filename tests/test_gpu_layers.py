@@ -790,3 +790,34 @@ def test_persistent_kernels_draw_their_tiles_while_others_hold_the_chip():
         launch(pa, stream())
     torch.cuda.synchronize()
     assert torch.equal(pa[5].interior(), refs[0])
+
+
+@pytest.mark.parametrize("N,H,W,epi", [(2, 32, 48, "lrelu"), (3, 16, 16, "none"), (64, 112, 112, "lrelu")])
+def test_small_channel_3x3_kernel_equals_the_tiled_one(N, H, W, epi):
+    """conv_c64.hip (tile_hint 22): 3x3 / stride-1 conv of 64 -> 64 channels with the weight panel resident in LDS and the input patch of a 16 x 16
+    tile staged once (ResNet-50's first-stage 3x3 convs: src/yolo/models.py:131-176).  K blocks in the implicit GEMM's order, the same MFMA:
+    bit-identical to the tiled kernel (tile_hint 4), also at the real size (64 x 112 x 112: 3136 tiles over 256 workgroups, double-buffered patches);
+    the halo of the output buffer stays untouched; shapes it does not take are refused."""
+    from yolo import engine
+    from yolo._hip import HipUnsupported, lib, ptr, stream
+    d, a_in, w, b, aux, a_out = _persist_problem(N, 64, 64, 3, H, W, epi)
+    if epi == "lrelu" and N == 2:
+        d.slope = 0.0            # ReLU: what the folded BatchNorm + ReLU of the ResNet trunk runs
+
+    def run(pl):
+        a_out.t.fill_(7.0)
+        engine._run_plan_igemm(lib(), d, pl, a_in.p, ptr(w), ptr(b) if epi == "lrelu" else None, None, a_out.p, stream(), "test")
+        return a_out.interior().clone()
+
+    ref = run((4, 1))
+    got = run((22, 1))
+    assert torch.isfinite(got.float()).all()
+    assert torch.equal(got, ref), (got.float() - ref.float()).abs().max().item()
+    assert torch.equal(a_out.view()[:, 0], torch.full_like(a_out.view()[:, 0], 7.0)) and torch.equal(a_out.view()[:, :, 0], torch.full_like(a_out.view()[:, :, 0], 7.0))
+    if N == 2:
+        d2, a2, w2, b2, _, o2 = _persist_problem(2, 64, 64, 3, 24, 48, "lrelu")          # 24 rows: not a multiple of 16
+        with pytest.raises(HipUnsupported):
+            engine._run_plan_igemm(lib(), d2, (22, 1), a2.p, ptr(w2), ptr(b2), None, o2.p, stream(), "test")
+        d3, a3, w3, b3, _, o3 = _persist_problem(2, 128, 64, 3, 32, 48, "lrelu")         # 128 input channels
+        with pytest.raises(HipUnsupported):
+            engine._run_plan_igemm(lib(), d3, (22, 1), a3.p, ptr(w3), ptr(b3), None, o3.p, stream(), "test")

@@ -865,6 +865,7 @@ YOLO_API int yolo_igemm(const yolo_igemm_desc *d, const void *in, const void *w,
         return launch<256, 208, 32, 4, 2, 4, MFMA_16x16x32_STAGGER_U>(p, splits, s);
     }
     if (force >= 15 && force <= 18) return igemm_pipe_launch(p, force, splits, s);     // register-pipelined one-barrier loop (igemm_pipe.hip)
+    if (force == 22) return conv_c64_launch(p, s);                                      // 3x3 64 -> 64: weights resident in LDS, patch staged once per tile (conv_c64.hip)
     if (force == 19) return igemm_stream_launch(p, splits, s);                          // streaming 1x1 convolution, thin K (igemm_stream.hip)
     if (force == 13) return launch<256, 128, 32, 4, 2, 4, MFMA_16x16x32_STAGGER>(p, splits, s);
     if (force == 10) return launch<64, 128, 32, 2, 2, 2>(p, splits, s);     // 28 KB of LDS: five workgroups per CU (thin-K 1x1 layers)

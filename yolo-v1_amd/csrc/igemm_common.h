@@ -93,5 +93,7 @@ int igemm_pipe_launch(const IgemmParams &p, int hint, int splits, hipStream_t s)
 int igemm_persist_launch(const IgemmParams &p, int hint, int splits, hipStream_t s);
 // igemm_stream.hip: streaming 1x1 convolution of the thin-K pointwise layers (tile_hint 19)
 int igemm_stream_launch(const IgemmParams &p, int splits, hipStream_t s);
+// conv_c64.hip: 3x3 / stride-1 conv of 64 -> 64 channels with the weight panel resident in LDS and the input patch staged once per tile (tile_hint 22)
+int conv_c64_launch(const IgemmParams &p, hipStream_t s);
 
 }  // namespace yolo

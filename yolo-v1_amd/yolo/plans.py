@@ -77,7 +77,8 @@ def _flush_caches(dev):
 # tile edge (co, px slots) of the configurations the tuner may combine
 _TILE = {1: (128, 128), 3: (128, 64), 4: (64, 128), 5: (128, 128), 10: (64, 128), 11: (256, 128), 12: (256, 256), 13: (256, 128), 14: (256, 208),
          15: (256, 208), 16: (256, 224), 17: (128, 208), 18: (128, 224), 19: (64, 16),       # (19: the streaming 1x1 kernel works in 16-pixel groups)
-         20: (256, 208), 21: (256, 224)}                                                     # persistent kernels (igemm_persist.hip)
+         20: (256, 208), 21: (256, 224),                                                     # persistent kernels (igemm_persist.hip)
+         22: (64, 256)}                                                                      # 3x3 64 -> 64, weights resident in LDS, 16 x 16-pixel tiles (conv_c64.hip)
 _TAIL_CANDIDATES = (5, 3, 4)
 # (workgroup slots of the chip, relative time of one tile) per configuration, for _default_plan: 8-wave configurations run
 # one workgroup per CU, the 4-wave ones two; times are relative to a 256x256 tile and follow the measured in-tile rates
@@ -155,6 +156,8 @@ def _run_plan_igemm(L_, d: IgemmDesc, plan, inp, w, bias, aux, out, st, what):
             plan = (14, plan[1])
         elif isinstance(plan[0], int) and plan[0] == 19 and d.epilogue != EPI_NONE:
             plan = (10, plan[1])           # the streaming 1x1 kernel accumulates statistics of raw conv outputs only
+        elif isinstance(plan[0], int) and plan[0] == 22:
+            plan = (4, plan[1])            # conv_c64.hip has no statistics epilogue
     d.tile_px, d.px_begin, d.px_end, d.skew_phases, d.skew_step = 0, 0, 0, 0, 0
     if plan[0] in ("splitk", "slabs"):
         # few-pixel deep-K layer: S workgroups per output tile into a dense fp32 scratch (atomics, or one slab per split),
@@ -240,6 +243,9 @@ def _tune(L_, d: IgemmDesc, inp, w, bias, aux, out, st, what):
     if d.KH == 1 and d.KW == 1 and not d.pool2:
         if d.tap_len in (64, 128, 192, 256, 512) and d.Cout % 64 == 0 and (d.N * d.Ho * d.Wo) % 16 == 0 and not d.out_fp32 and d.split_k <= 1:
             cands.append(19)  # ... or the streaming 1x1 kernel (igemm_stream.hip): weight panel in LDS, activations straight into MFMA fragments
+    if (d.KH == 3 and d.KW == 3 and d.tap_len == 64 and d.Cout == 64 and d.stride == 1 and d.Ho % 16 == 0 and d.Wo % 16 == 0 and not d.pool2 and not d.out_fp32
+            and d.epilogue in (EPI_NONE, EPI_BIAS, EPI_BIAS_LRELU)):
+        cands.append(22)      # ResNet-50's first-stage 3x3 convs: weight panel resident in LDS, input patch staged once per 16 x 16 tile (conv_c64.hip)
     orders = (1, 2) if (d.Cout * d.KH * d.KW * d.tap_len * 2 > (4 << 20) and d.Cout >= 1024) else (1,)
     for c in cands:
         for o in orders:
