@@ -167,7 +167,7 @@ typedef struct yolo_igemm_desc {
                                pipeline over all tiles of a workgroup, tiles of 256 x 208 / 224 drawn from per-XCD queues, epilogue out of the
                                accumulator registers), 22: 3x3 / stride-1 conv of 64 -> 64 channels on maps of (16k) x (16k) pixels with the weight
                                panel resident in LDS and the input patch of a 16 x 16 tile staged once (conv_c64.hip; epilogue NONE / BIAS /
-                               BIAS_LRELU, bf16 out, no pool2 / bn_stats / split_k)  (tuning / tests;
+                               BIAS_LRELU, bf16 out, bn_stats allowed, no pool2 / split_k)  (tuning / tests;
                                a caller that wants the best plan times them per problem, as engine.igemm_call does) */
     int64_t px_begin, px_end; /* compute only output pixels [px_begin, px_end) of the flattened (n, oy, ox) index
                                (0, 0 = all).  Lets a caller run the bulk of a layer with a large tile in whole

@@ -792,7 +792,7 @@ def test_persistent_kernels_draw_their_tiles_while_others_hold_the_chip():
     assert torch.equal(pa[5].interior(), refs[0])
 
 
-@pytest.mark.parametrize("N,H,W,epi", [(2, 32, 48, "lrelu"), (3, 16, 16, "none"), (64, 112, 112, "lrelu")])
+@pytest.mark.parametrize("N,H,W,epi", [(2, 32, 48, "lrelu"), (3, 16, 16, "none"), (16, 64, 48, "none"), (64, 112, 112, "lrelu")])
 def test_small_channel_3x3_kernel_equals_the_tiled_one(N, H, W, epi):
     """conv_c64.hip (tile_hint 22): 3x3 / stride-1 conv of 64 -> 64 channels with the weight panel resident in LDS and the input patch of a 16 x 16
     tile staged once (ResNet-50's first-stage 3x3 convs: src/yolo/models.py:131-176).  K blocks in the implicit GEMM's order, the same MFMA:
@@ -821,3 +821,17 @@ def test_small_channel_3x3_kernel_equals_the_tiled_one(N, H, W, epi):
         d3, a3, w3, b3, _, o3 = _persist_problem(2, 128, 64, 3, 32, 48, "lrelu")         # 128 input channels
         with pytest.raises(HipUnsupported):
             engine._run_plan_igemm(lib(), d3, (22, 1), a3.p, ptr(w3), ptr(b3), None, o3.p, stream(), "test")
+    if epi == "none":
+        # yolo_igemm_desc.bn_stats (the raw conv of the ResNet trunk in training mode): per-channel sum and sum of squares of the values AS STORED, spread over
+        # the accumulator replicas; same output bits
+        from yolo._hip import BN_ACC_REPLICAS
+        acc = torch.zeros(BN_ACC_REPLICAS * 2 * 64, dtype=torch.float64, device="cuda")
+        d.bn_stats = acc.data_ptr()
+        try:
+            got_s = run((22, 1))
+        finally:
+            d.bn_stats = None
+        assert torch.equal(got_s, ref)
+        tot = acc.view(BN_ACC_REPLICAS, 2, 64).sum(0)
+        y = ref.double().reshape(-1, 64)
+        assert torch.allclose(tot[0], y.sum(0), rtol=1e-5, atol=1e-3) and torch.allclose(tot[1], (y * y).sum(0), rtol=1e-5, atol=1e-3)

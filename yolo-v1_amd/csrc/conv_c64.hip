@@ -46,6 +46,10 @@ __device__ __forceinline__ int c64_pos(int pi, int c)
     return c ^ (2 * ((pi >> 1) & 3));
 }
 
+// STATS: BatchNorm's per-channel sum / sum of squares of the stored (bf16-rounded) outputs as well (yolo_igemm_desc.bn_stats, epilogue NONE: the raw conv of the
+// ResNet trunk in training mode).  In the store phase a thread always handles the same 8-channel chunk (tid & 7), so its sixteen partial sums live in registers
+// for the workgroup's whole walk; one fold through LDS and 128 fp64 atomics per workgroup at the end.
+template <bool STATS>
 __global__ void __launch_bounds__(c64::NTHR) conv_c64_kernel(const IgemmParams p, int tiles_x, int tiles_y, int ntiles)
 {
     using namespace c64;
@@ -113,6 +117,7 @@ __global__ void __launch_bounds__(c64::NTHR) conv_c64_kernel(const IgemmParams p
             for (int cb = 0; cb < 2; ++cb) b_addr[rr][tap][cb] = pi * 128 + c64_pos(pi, cb * 4 + kb) * 16;
         }
 
+    float red[16] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
     for (int it = 0; tile < ntiles; ++it, tile += gridDim.x) {
         const int buf = it & 1;
         const char *sb = patch + buf * PATCH_BYTES;
@@ -192,7 +197,34 @@ __global__ void __launch_bounds__(c64::NTHR) conv_c64_kernel(const IgemmParams p
         for (int j = 0; j < TH * TW * 8 / NTHR; ++j) {
             const int q = j * NTHR + tid, px = q >> 3, c8 = q & 7;
             const int oy = px / TW, ox = px - oy * TW;
-            *reinterpret_cast<uint4 *>(ob + (long)oy * p.out_row_stride + ox * p.out_px_stride + c8 * 8) = *reinterpret_cast<const uint4 *>(otile + px * OP + c8 * 8);
+            const uint4 pk = *reinterpret_cast<const uint4 *>(otile + px * OP + c8 * 8);
+            *reinterpret_cast<uint4 *>(ob + (long)oy * p.out_row_stride + ox * p.out_px_stride + c8 * 8) = pk;
+            if constexpr (STATS) {
+                const unsigned w4[4] = {pk.x, pk.y, pk.z, pk.w};
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const float r = __uint_as_float((k & 1) ? (w4[k >> 1] & 0xffff0000u) : (w4[k >> 1] << 16));   // the value as stored
+                    red[k] += r;
+                    red[8 + k] += r * r;
+                }
+            }
+        }
+    }
+    if constexpr (STATS) {
+        // fold the 64 threads of each channel chunk (tid & 7) through LDS, then one fp64 atomic pair per channel into one of YOLO_BN_ACC_REPLICAS accumulators
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        float *all = reinterpret_cast<float *>(patch);
+#pragma unroll
+        for (int k = 0; k < 16; ++k) all[tid * 16 + k] = red[k];
+        __syncthreads();
+        if (tid < 64) {
+            const int c8 = tid >> 3, k = tid & 7;
+            float a = 0.0f, b = 0.0f;
+            for (int j = 0; j < NTHR / 8; ++j) { a += all[(j * 8 + c8) * 16 + k]; b += all[(j * 8 + c8) * 16 + 8 + k]; }
+            double *rep = p.stats + (size_t)(blockIdx.x % YOLO_BN_ACC_REPLICAS) * 2 * 64;
+            atomicAdd(rep + tid, (double)a);
+            atomicAdd(rep + 64 + tid, (double)b);
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // no LDS-DMA may outlive the workgroup
@@ -202,7 +234,7 @@ int conv_c64_launch(const IgemmParams &p, hipStream_t s)
 {
     using namespace c64;
     const int Ho = p.HoWo / p.Wo, Wo = p.Wo;
-    if (p.KH != 3 || p.KW != 3 || p.stride != 1 || p.tap_len != 64 || p.Cout != 64 || p.out_fp32 || p.pool || p.w_blocked || p.stats || p.px_begin != 0 ||
+    if (p.KH != 3 || p.KW != 3 || p.stride != 1 || p.tap_len != 64 || p.Cout != 64 || p.out_fp32 || p.pool || p.w_blocked || p.px_begin != 0 ||
         (p.epilogue != YOLO_EPI_NONE && p.epilogue != YOLO_EPI_BIAS && p.epilogue != YOLO_EPI_BIAS_LRELU) || (Ho % TH) || (Wo % TW) || (p.in_px_stride & 7) ||
         (p.in_row_stride & 7) || (p.in_img_stride & 7) || (p.in_off & 7) || (p.out_px_stride & 7) || (p.out_row_stride & 7) || (p.out_img_stride & 7) || (p.out_off & 7))
         return fail(YOLO_E_UNSUPPORTED, "yolo_igemm: tile_hint 22 is the 3x3 / stride-1 conv of 64 -> 64 channels on maps of (16k) x (16k) pixels, bf16 out, 16-B aligned strides");
@@ -211,7 +243,8 @@ int conv_c64_launch(const IgemmParams &p, hipStream_t s)
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
     if (!attr_done[dev]) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_c64_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_c64_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_c64_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
         if (e != hipSuccess) return fail((int)e, "yolo_igemm: hipFuncSetAttribute(%d B LDS): %s", LDS_BYTES, hipGetErrorString(e));
         int n = 0;
         if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
@@ -221,7 +254,8 @@ int conv_c64_launch(const IgemmParams &p, hipStream_t s)
     const int tiles_x = Wo / TW, tiles_y = Ho / TH;
     const long ntiles = (long)(p.M / p.HoWo) * tiles_x * tiles_y;
     const int G = (int)std::min<long>(ntiles, cus[dev]);
-    hipLaunchKernelGGL(conv_c64_kernel, dim3(G), dim3(NTHR), LDS_BYTES, s, p, tiles_x, tiles_y, (int)ntiles);
+    if (p.stats) hipLaunchKernelGGL(conv_c64_kernel<true>, dim3(G), dim3(NTHR), LDS_BYTES, s, p, tiles_x, tiles_y, (int)ntiles);
+    else hipLaunchKernelGGL(conv_c64_kernel<false>, dim3(G), dim3(NTHR), LDS_BYTES, s, p, tiles_x, tiles_y, (int)ntiles);
     return check_launch("yolo_igemm (3x3 64 -> 64)");
 }
 

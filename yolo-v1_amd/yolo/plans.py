@@ -156,8 +156,6 @@ def _run_plan_igemm(L_, d: IgemmDesc, plan, inp, w, bias, aux, out, st, what):
             plan = (14, plan[1])
         elif isinstance(plan[0], int) and plan[0] == 19 and d.epilogue != EPI_NONE:
             plan = (10, plan[1])           # the streaming 1x1 kernel accumulates statistics of raw conv outputs only
-        elif isinstance(plan[0], int) and plan[0] == 22:
-            plan = (4, plan[1])            # conv_c64.hip has no statistics epilogue
     d.tile_px, d.px_begin, d.px_end, d.skew_phases, d.skew_step = 0, 0, 0, 0, 0
     if plan[0] in ("splitk", "slabs"):
         # few-pixel deep-K layer: S workgroups per output tile into a dense fp32 scratch (atomics, or one slab per split),
