@@ -17,12 +17,12 @@ resnet = os.environ.get("MODEL", "yolov1") == "resnet50"
 train = os.environ.get("TRAIN", "0") == "1"
 m = (YOLOv1(backbone=ResNetBackbone(pretrained=False, freeze=not train)) if resnet else YOLOv1()).cuda()
 m = m.train() if train else m.eval()
-x = torch.randn(64, 3, 448, 448, device="cuda")
+x = torch.randn(int(os.environ.get("BATCH", "64")), 3, 448, 448, device="cuda")
 if train:
     sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
     import synth
     from yolo import YOLOLoss
-    tgt = torch.from_numpy(synth.synth_targets(64, seed=1)).cuda()
+    tgt = torch.from_numpy(synth.synth_targets(int(os.environ.get("BATCH", "64")), seed=1)).cuda()
     crit = YOLOLoss()
     _fwd = m
 
