@@ -195,8 +195,15 @@ __global__ void __launch_bounds__(WCO * WPX * 64, (TCO == 64 && TPX == 128 && BK
         const int kiter = interleave ? (int)blockIdx.y + kiter_local * kstep : kiter_local;
         const long a_off = (long)kiter * (p.w_blocked ? TCO * BK : BK);
         const long b_off = interleave ? (long)kiter * BK : (long)ky * p.in_row_stride + (long)kx * p.in_px_stride + c0;
+        if (p.w_blocked) {
+            // the blocked panels of a Linear layer are read exactly once per forward (411 MB for the one behind nn.Flatten): non-temporal policy, so the
+            // stream does not push the activations out of L2 / Infinity Cache (94 -> 85-91 us at batch 64)
 #pragma unroll
-        for (int i = 0; i < Cfg::A_INSTR; ++i) GLDS16(a_src[i] + a_off, sb + a_dst[i]);
+            for (int i = 0; i < Cfg::A_INSTR; ++i) GLDS16_NT(a_src[i] + a_off, sb + a_dst[i]);
+        } else {
+#pragma unroll
+            for (int i = 0; i < Cfg::A_INSTR; ++i) GLDS16(a_src[i] + a_off, sb + a_dst[i]);
+        }
 #pragma unroll
         for (int i = 0; i < Cfg::B_INSTR; ++i) GLDS16(b_src[i] + b_off, sb + b_dst[i]);
         c0 += BK;
