@@ -15,9 +15,10 @@ CHILD = os.path.join(ROOT, "tests", "dist_child.py")
 pytestmark = pytest.mark.gpu
 
 
-def _run(args, timeout=600):
+def _run(args, timeout=600, **extra_env):
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.update(extra_env)
     r = subprocess.run([sys.executable] + args, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
     assert r.returncode == 0, f"{args}\n--- stdout\n{r.stdout[-2000:]}\n--- stderr\n{r.stderr[-4000:]}"
     return r
@@ -54,16 +55,17 @@ def test_rccl_world1_overlapped_path_equals_single_process_step(tmp_path):
         torch.testing.assert_close(b["params"][n], p, rtol=1e-5, atol=1e-7, msg=n)
 
 
-def test_two_ranks_on_one_gpu_equal_the_single_process_step_on_the_whole_batch(tmp_path):
+@pytest.mark.parametrize("small_split", ["0", "1"])
+def test_two_ranks_on_one_gpu_equal_the_single_process_step_on_the_whole_batch(tmp_path, small_split):
     """at world size 1 a mean over ranks is the identity.  Two ranks (gloo; both on this box's one GPU) each take half of
     the batch through the shipped path -- gradient arena, bucketed all-reduce overlapped with the two-stream backward pass, fused
     clip + Adam: the ranks end bit-identical, and equal to the single-process step on all four images up to what a different batch
     size changes (other launch plans -> other fp32 summation orders -> a few bf16 roundings)."""
     plain, two = tmp_path / "plain.pt", tmp_path / "two.pt"
-    _run([CHILD, "plain", str(plain)])
-    port = 29900 + os.getpid() % 300
+    _run([CHILD, "plain", str(plain)], YOLO_AMD_SMALL_SPLIT=small_split)
+    port = 29900 + os.getpid() % 300 + 300 * int(small_split)
     _run(["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
-          CHILD, "gloo2", str(two)], timeout=900)
+          CHILD, "gloo2", str(two)], timeout=900, YOLO_AMD_SMALL_SPLIT=small_split)
     a = torch.load(plain, weights_only=True)
     r0 = torch.load(str(two) + ".r0", weights_only=True)
     r1 = torch.load(str(two) + ".r1", weights_only=True)
@@ -74,9 +76,18 @@ def test_two_ranks_on_one_gpu_equal_the_single_process_step_on_the_whole_batch(t
         assert torch.equal(r0["grads"][n], r1["grads"][n]), n
     # mean of the two shard losses = loss of the whole batch (YOLOLoss divides by the local N, shards are equal)
     assert abs(0.5 * (r0["loss"] + r1["loss"]) - a["loss"]) <= 2e-3 * abs(a["loss"])
+    # small_split = "0" (config.SMALL_SPLIT off: every few-pixel layer is ONE plain launch at 2 and at 4 images -> the same fp32 summation orders):
+    # the plumbing is compared at the tolerance of a few bf16 roundings.  "1" (the default): the deep layers split their K range by the number
+    # of pixel tiles, so their fp32 sums are taken in another order at 2 and at 4 images -- 0.1-0.3 % of a gradient's norm at the head end of
+    # the backward pass, growing to 1-2.6 % (cosine 0.975) at the first layers of this random-init LeakyReLU network, whose gates flip under a
+    # rounding; the split itself is pinned against fp64 in test_gpu_layers.py::test_k_range_slabs_of_one_layer_equal_the_fp64_product
+    tol, cos_min = (2e-2, 0.995) if small_split == "0" else (5e-2, 0.95)
+    print("norm deviations:", {n: round(abs(r0["norms"][n] - v) / (v + 1e-30), 4) for n, v in a["norms"].items()})
     for n, v in a["norms"].items():
-        assert abs(r0["norms"][n] - v) <= 2e-2 * v + 1e-9, (n, r0["norms"][n], v)
+        assert abs(r0["norms"][n] - v) <= tol * v + 1e-9, (n, r0["norms"][n], v)
     for n, g in a["grads"].items():
         gg = r0["grads"][n].double().flatten()
         cos = float((gg * g.double().flatten()).sum() / (gg.norm() * g.double().norm() + 1e-30))
-        assert cos > 0.995, (n, cos)
+        assert cos > cos_min, (n, cos)
+        if n.startswith("head.4."):
+            assert cos > 0.9995, (n, cos)          # behind no LeakyReLU gate: rounding level either way

@@ -17,8 +17,12 @@ torch.manual_seed(0)
 model = (YOLOv1(backbone=ResNetBackbone(pretrained=False, freeze=True)) if resnet else YOLOv1()).to(dev).eval()
 gf = 40.57 if not resnet else None
 shipped = set(engine._TUNED)
+if os.environ.get("NO_SMALL_SPLIT") == "1":      # A/B of the default rule for few-pixel deep-K problems: one plain launch, as before round 3
+    from yolo import plans
+    _dp = plans._default_plan
+    plans._default_plan = lambda d: (0, 0) if (not d.pool2 and d.N * d.Ho * d.Wo < 2048) else _dp(d)
 rows = []
-for B in (1, 13, 16, 32, 64):
+for B in tuple(int(b) for b in os.environ.get("BATCHES", "1,13,16,32,64").split(",")):
     x = torch.randn(B, 3, 448, 448, device=dev)
     before = set(engine._TUNED)
     with torch.no_grad():

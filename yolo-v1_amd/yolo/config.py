@@ -22,6 +22,7 @@ class EngineConfig:
     AUTOTUNE: bool = False           # tools/tune_plans.py only: time the candidate plans of a problem without a table entry
     TILE_HINT: int = 0               # tests / tuning: force a tile configuration of yolo_igemm (0 = plan table; yolo_igemm_desc.tile_hint)
     TILE_PX: int = 0                 # with TILE_HINT: yolo_igemm_desc.tile_px of the forced configuration
+    SMALL_SPLIT: bool = True         # problems without a table entry, < 2048 pixels under a deep K (small batches on the 14x14 / 7x7 maps): K ranges as slabs (False: one plain launch)
     PERSIST: bool = True             # plans with the persistent kernels (tile_hint 20 / 21) run them (False: the pipelined kernels 15 / 16 -- A/B runs)
     # ---- what is fused
     BN_STATS_IN_CONV: bool = True    # ResNet trunk in batch-statistics mode: BatchNorm's sums come out of the conv's epilogue (yolo_igemm_desc.bn_stats)
@@ -47,5 +48,19 @@ class EngineConfig:
     WGRAD_WIDE: bool = True          # ... variant 6 (wgrad_wide.hip: four waves of 128 x 128, accumulators in AGPRs) instead of 5, and on more layers
 
 
-CONFIG = EngineConfig()
+def _from_env(cfg: EngineConfig) -> EngineConfig:
+    """YOLO_AMD_<SWITCH>=0|1|<int> in the environment sets a bool / int switch of the process-wide default (A/B runs of entry points and of
+    the multi-process tests without editing code); anything else in such a variable is an error, not ignored"""
+    import os
+    for f in fields(EngineConfig):
+        v = os.environ.get("YOLO_AMD_" + f.name)
+        if v is None:
+            continue
+        if f.type not in ("bool", "int"):
+            raise ValueError(f"YOLO_AMD_{f.name}: only the bool / int switches can be set from the environment")
+        setattr(cfg, f.name, bool(int(v)) if f.type == "bool" else int(v))
+    return cfg
+
+
+CONFIG = _from_env(EngineConfig())
 SWITCHES = frozenset(f.name for f in fields(EngineConfig))

@@ -116,6 +116,18 @@ def _default_plan(d: IgemmDesc):
             return ("tile", 21, 1, 0)
         return ("tile", 16 if d.Cout > 128 else 18, 1, 0)
     if M < 2048:
+        # a handful of pixel tiles (small batches on the 14x14 / 7x7 maps) under a deep K: without a split a few workgroups walk hundreds of K steps while
+        # the chip idles -- K ranges of 64 x 128 tiles as slabs, enough of them for two workgroups per CU (batch 1, measured: 90 -> 17-21 us per layer)
+        ktot = d.KH * d.KW * d.tap_len
+        if (CFG.SMALL_SPLIT and ktot >= 2304 and d.tap_len % 64 == 0 and d.Cout % 8 == 0 and not d.out_fp32 and not d.bn_stats and d.split_k <= 1
+                and d.epilogue in (EPI_NONE, EPI_BIAS, EPI_BIAS_LRELU, EPI_MUL_DLRELU)):
+            hint = 3 if (M + 63) // 64 * 64 < (M + 127) // 128 * 128 else 4       # 128 co x 64 px where that wastes fewer pixel rows, else 64 co x 128 px
+            tco, tpx = _TILE[hint]
+            tiles = ((d.Cout + tco - 1) // tco) * ((M + tpx - 1) // tpx)
+            S = 2
+            while S < 32 and tiles * S < 512 and (ktot // 64) // (2 * S) >= 8:      # two 4-wave workgroups per CU; >= 8 K steps of 64 per range
+                S *= 2
+            return ("slabs", hint, S, 0)
         return (0, 0)
     if _persist_ok(d) and d.Cout >= 192 and M * ((d.Cout + 255) // 256) >= 96 * 208:
         # the persistent kernel (one software pipeline over a workgroup's tiles, epilogue out of the registers) won 42 of the 90 problems
@@ -303,6 +315,13 @@ def _tune(L_, d: IgemmDesc, inp, w, bias, aux, out, st, what):
             and d.epilogue in (EPI_NONE, EPI_BIAS, EPI_BIAS_LRELU, EPI_MUL_DLRELU)):
         for c, S, tpv in ((11, 2, 0), (5, 2, 0), (3, 2, 0), (14, 4, tile_px), (15, 4, tile_px), (15, 2, tile_px), (12, 4, 0), (11, 4, 0)):
             consider(("slabs", c, S, tpv))
+        if M < 2048:
+            # a handful of pixel tiles (batch 1: 196 or 49 pixels): many K ranges of small tiles so that the weight stream is spread over the chip
+            nks = d.KH * d.KW * d.tap_len // 64
+            for c in (5, 3, 4):
+                for S in (4, 8, 16, 32):
+                    if nks // S >= 2:
+                        consider(("slabs", c, S, 0))
         if d.Cout % 256 == 0 and d.tap_len % 32 == 0:
             for S in (2, 4, 8):       # the persistent kernel, K ranges as extra tiles (each range: an even number >= 6 of K steps)
                 nks = d.KH * d.KW * d.tap_len // 32
@@ -331,7 +350,9 @@ def igemm_call(d: IgemmDesc, inp, w, bias, aux, out, st, what: str):
     key = _tune_key(d)
     best = _TUNED.get(key)
     if best is None:
-        if CFG.AUTOTUNE and CFG.TIMERS is None and d.N * d.Ho * d.Wo >= 2048:
+        # (few-pixel problems are tuned too when their weight panel is large: at batch 1 the 14x14 / 7x7 layers are a handful of workgroups walking
+        # 288 K steps each unless the K range is split over the chip)
+        if CFG.AUTOTUNE and CFG.TIMERS is None and (d.N * d.Ho * d.Wo >= 2048 or d.KH * d.KW * d.tap_len * d.Cout >= (1 << 20)):
             best = _tune(L_, d, inp, w, bias, aux, out, st, what)
         else:
             best = _default_plan(d)
