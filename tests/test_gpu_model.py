@@ -565,6 +565,34 @@ def test_frozen_resnet_backbone_in_training_mode():
         assert hg[n].grad is not None and report[n] < (0.08 if "fc_layers.4" not in n else 0.01), report
 
 
+@pytest.mark.parametrize("n", [1, 2, 5])
+def test_small_batches_unfuse_the_few_tile_pool_convs(model, n):
+    """serving batches: with config.SMALL_SPLIT the deep-K convs in front of a pool that would give the pooled kernel less than a quarter of the chip
+    run un-fused (K ranges as slabs + the pool as its own pass, executor.Plan._few_tiles) -- same predictions as the fused launches up to the
+    rounding of another fp32 summation order, and the un-fused pool passes are really there."""
+    from yolo import engine
+    g = model.cuda().eval()
+    torch.manual_seed(31)
+    x = torch.randn(n, 3, 448, 448, device="cuda")
+    out, tags = {}, {}
+    for on in (True, False):
+        engine.SMALL_SPLIT = on
+        try:
+            with torch.no_grad():
+                g(x)
+                engine.TIMERS = []
+                out[on] = g(x).float().clone()
+                torch.cuda.synchronize()
+                tags[on] = [t[0] for t in engine.TIMERS]
+        finally:
+            engine.TIMERS = None
+            engine.SMALL_SPLIT = True
+    assert not any(t.startswith("pool") for t in tags[False]), tags[False]            # every pool fused into its conv
+    assert ("pool19" in tags[True] and "conv18" in tags[True]) == (n <= 4), tags[True]  # 28x28, 512 -> 1024: 16 tiles of 224 x 256 at batch 1, 72 at 5
+    assert ("pool8" in tags[True]) == (n <= 2), tags[True]                             # 56x56, 256 -> 512: 28 tiles at batch 1, 56 at 2, 140 at 5
+    assert _rel(out[True], out[False]) < 0.01, _rel(out[True], out[False])
+
+
 def test_gradient_arena_equals_autograd_path(model):
     """data-parallel plumbing on one GPU: with the gradient arena attached, backward writes the same
     gradients into the flat buffer, assigns p.grad views, and fires the bucket callbacks in arena order

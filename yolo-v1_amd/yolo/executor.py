@@ -407,6 +407,13 @@ class Plan:
         return (not L.first and L.Cin % 32 == 0 and nk % 2 == 0 and nk >= 4 and L.Wout in (112, 56, 28) and L.Hout % 2 == 0
                 and (L.Hout * L.Wout) % 112 == 0)
 
+    def _few_tiles(self, L: Layer, N: int) -> bool:
+        """small batches: a deep-K conv in front of a pool whose pooled kernel would have work for less than a quarter of the chip (batch 1: conv18 = 4
+        pixel tiles x 4 channel tiles under K = 4608, 83 us) runs un-fused -- K ranges as slabs over the whole chip (plans._default_plan / the tuner's
+        slab candidates; the pooled epilogue has no split form) and the pool as its own small pass (config.SMALL_SPLIT)"""
+        tiles = ((N * L.Hout * L.Wout + 223) // 224) * ((L.Cout + 255) // 256)
+        return bool(self.c.SMALL_SPLIT and not L.first and tiles < 64 and L.K * L.K * L.Cin >= 2304 and L.Cin % 64 == 0)
+
     # ------------------------------------------------------------------ forward
     @_hip.device_guard
     def forward(self, x: torch.Tensor, train: bool, drop_training: bool, u8_size=None):
@@ -466,7 +473,7 @@ class Plan:
                 # 8 x 16 pixel patches (the first two layers: 224^2 and 112^2); training keeps the un-pooled
                 # activation, which the backward pass needs
                 fuse = (not train and self.c.FUSE_POOL and li + 1 < len(self.layers) and self.layers[li + 1].kind == "pool"
-                        and self._pool_fusable(L))
+                        and self._pool_fusable(L) and not self._few_tiles(L, N))
                 if fuse:
                     nxt = ws["acts"][li + 1]
                 d = self._conv_desc(L, cur, nxt)

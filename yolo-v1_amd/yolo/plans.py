@@ -115,7 +115,7 @@ def _default_plan(d: IgemmDesc):
         if _persist_ok(d) and d.pool2 in (1, 3) and M % 224 == 0 and d.Cout > 128:
             return ("tile", 21, 1, 0)
         return ("tile", 16 if d.Cout > 128 else 18, 1, 0)
-    if M < 2048:
+    if M < 2048 or (M < 8192 and ((d.Cout + 63) // 64) * ((M + 127) // 128) < 256):
         # a handful of pixel tiles (small batches on the 14x14 / 7x7 maps) under a deep K: without a split a few workgroups walk hundreds of K steps while
         # the chip idles -- K ranges of 64 x 128 tiles as slabs, enough of them for two workgroups per CU (batch 1, measured: 90 -> 17-21 us per layer)
         ktot = d.KH * d.KW * d.tap_len
@@ -128,7 +128,8 @@ def _default_plan(d: IgemmDesc):
             while S < 32 and tiles * S < 512 and (ktot // 64) // (2 * S) >= 8:      # two 4-wave workgroups per CU; >= 8 K steps of 64 per range
                 S *= 2
             return ("slabs", hint, S, 0)
-        return (0, 0)
+        if M < 2048:
+            return (0, 0)
     if _persist_ok(d) and d.Cout >= 192 and M * ((d.Cout + 255) // 256) >= 96 * 208:
         # the persistent kernel (one software pipeline over a workgroup's tiles, epilogue out of the registers) won 42 of the 90 problems
         # measured at batch 64, every one with >= 192 output channels and enough tiles for half the chip; 196-pixel tiles where they
@@ -315,7 +316,7 @@ def _tune(L_, d: IgemmDesc, inp, w, bias, aux, out, st, what):
             and d.epilogue in (EPI_NONE, EPI_BIAS, EPI_BIAS_LRELU, EPI_MUL_DLRELU)):
         for c, S, tpv in ((11, 2, 0), (5, 2, 0), (3, 2, 0), (14, 4, tile_px), (15, 4, tile_px), (15, 2, tile_px), (12, 4, 0), (11, 4, 0)):
             consider(("slabs", c, S, tpv))
-        if M < 2048:
+        if M < 2048 or ((d.Cout + 63) // 64) * ((M + 127) // 128) < 256:
             # a handful of pixel tiles (batch 1: 196 or 49 pixels): many K ranges of small tiles so that the weight stream is spread over the chip
             nks = d.KH * d.KW * d.tap_len // 64
             for c in (5, 3, 4):
