@@ -451,6 +451,25 @@ def main():
                "config": "64 decoded uint8 RGB images 375x500 resident in HBM -> Resize(448,448) (Pillow BILINEAR, bit-exact) + ToTensor + Normalize -> NHWC4 bf16",
                "forward_from_uint8": {"value": round(64 / dt_e, 1), "unit": "images/s", "ms_per_batch64": round(dt_e * 1e3, 3)}}
 
+    # ---------------------------------------------------------------- small batches: predict.py's single image (configs[0] runs it on the CPU), evaluate.py's 16
+    small = None
+    if rank == 0 and world == 1 and not a.no_nms:
+        small = {"unit": "ms per forward (YOLOv1Backbone + FC head, inputs resident, back-to-back forwards)",
+                 "note": "yolo/plans/gfx950.json holds measured plans for batches 1, 16 and 64; few-pixel deep-K layers split their K range over the chip (DESIGN.md section 7)"}
+        model.eval()
+        for nb in (1, 16):
+            xb = x[:nb].contiguous()
+            with torch.no_grad():
+                for _ in range(10):
+                    model(xb)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(100):
+                    model(xb)
+                torch.cuda.synchronize()
+            ms = 1e3 * (time.perf_counter() - t0) / 100
+            small[f"batch{nb}"] = {"ms": round(ms, 4), "images_per_s": round(nb / ms * 1e3, 1)}
+
     # ---------------------------------------------------------------- ResNet50 variant (configs[4])
     resnet = None
     if not a.no_resnet and rank == 0 and world == 1:
@@ -605,7 +624,7 @@ def main():
                        "flops_per_image": 40.57e9, "parallelism": f"dp{world}" if world > 1 else "single"},
             "roofline": roof, "cpu_baseline": cpu, "sustained": sustained, "first_forward_ms": round(first_forward_ms, 1),
             **({"rehearsal": "BENCH_REHEARSE=1: all ranks on ONE GPU over gloo -- a test of the N-rank code path, not a measurement"} if rehearse else {}),
-            "train": train, "nms": nms, "preprocess": pre, "resnet50_variant": resnet,
+            "train": train, "nms": nms, "preprocess": pre, "small_batches": small, "resnet50_variant": resnet,
         }
         print(json.dumps(out))
     if use_dist:
