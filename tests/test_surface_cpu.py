@@ -392,6 +392,26 @@ def test_bench_launches_its_own_ranks(monkeypatch, capsys):
     assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
 
 
+def test_a_launch_with_batchnorm_statistics_gets_a_kernel_that_has_them(monkeypatch):
+    """plans are keyed without yolo_igemm_desc.bn_stats, so a plan measured on the plain launch (inference, frozen statistics) also reaches the launch that
+    accumulates BatchNorm sums; only the tiled kernels (tile_hint 1 .. 14) have that epilogue, and it must be ONE launch: every plan form of the
+    pipelined / persistent kernels and every split falls back to its one-launch stand-in (found by tuning batch 32: ("slabs", 20, ..) -> tile_hint 20 raised)."""
+    from yolo import plans
+    from yolo._hip import IgemmDesc
+    seen = []
+    monkeypatch.setattr(plans, "_igemm", lambda L_, d, *a: seen.append((d.tile_hint, d.split_k, d.px_begin, d.px_end)))
+    for plan in (("slabs", 20, 4, 196), ("slabs", 15, 4, 196), ("slabs", 4, 16, 0), ("splitk", 5, 3), ("tile", 20, 1, 196), ("tile", 21, 1, 224), ("tile", 15, 1, 196),
+                 ("tile", 20, 1, 208, 3, 7000), ("skew", 15, 1, 3, 4000), (15, 1), (5, 1), (11, 1), (5, 1, 1024, 3)):
+        d = IgemmDesc()
+        d.N, d.Ho, d.Wo, d.KH, d.KW, d.tap_len, d.Cout, d.stride, d.split_k = 8, 14, 14, 3, 3, 512, 512, 1, 1
+        d.bn_stats = 1234
+        seen.clear()
+        plans._run_plan_igemm(None, d, plan, None, None, None, None, None, None, "test")
+        assert len(seen) == 1, (plan, seen)
+        hint, split, b, e = seen[0]
+        assert 1 <= hint <= 14 and split <= 1 and b == 0 and e == 0, (plan, seen)
+
+
 def test_shipped_plan_table_and_weight_gradient_choices(tmp_path):
     """yolo/plans/gfx950.json: every entry parses into a plan the engine knows, the "wgrad" section (kernel choices measured inside the
     training step, tools/search_wgrad.py) reaches Plan._wgrad_desc, and save_plans / load_plans round-trip both sections."""
@@ -404,7 +424,7 @@ def test_shipped_plan_table_and_weight_gradient_choices(tmp_path):
     assert body["arch"] == "gfx950" and len(body["plans"]) >= 200
     for k, v in body["plans"].items():
         key = tuple(int(t) for t in k.split(","))
-        assert len(key) == 12 and key[0] in (1, 16, 64), k
+        assert len(key) == 12 and key[0] in (1, 2, 4, 8, 16, 32, 64), k
         assert isinstance(v[0], int) or v[0] in ("tile", "slabs", "splitk", "skew"), (k, v)
     choice = CONFIG.WGRAD_CHOICE
     assert choice and all(len(k) == 7 and v[0] in (0, 5, 6) and v[1] in (0, 1) for k, v in choice.items())

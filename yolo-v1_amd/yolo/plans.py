@@ -154,7 +154,8 @@ def _run_plan_igemm(L_, d: IgemmDesc, plan, inp, w, bias, aux, out, st, what):
     """run one yolo_igemm problem with a launch plan (forms: see above)"""
     if d.bn_stats and (plan[0] in ("splitk", "slabs") or (isinstance(plan[0], int) and len(plan) == 4)):
         # a launch that also accumulates BatchNorm statistics must be one plain launch: keep the plan's main configuration
-        plan = (plan[1], 1) if plan[0] in ("splitk", "slabs") else (plan[0], plan[1])
+        # (a slab plan of the pipelined / persistent kernels, measured on the launch without statistics: their one-launch stand-in is the staggered loop)
+        plan = ((14 if plan[1] in (15, 16, 17, 18, 20, 21) else plan[1]), 1) if plan[0] in ("splitk", "slabs") else (plan[0], plan[1])
     if plan[0] == "tile" and plan[1] in (20, 21) and (d.pool2 == 2 or not CFG.PERSIST or not _persist_ok(d)):
         # the persistent kernels pool with pool2 = 1 (inference) and 3 (training: pooled map + arg-max codes; a plan measured for
         # pool2 = 1 also serves pool2 = 3, see _tune_key); pooled map + un-pooled activation (pool2 = 2), and anything else they do not
