@@ -62,10 +62,11 @@ def test_two_ranks_on_one_gpu_equal_the_single_process_step_on_the_whole_batch(t
     clip + Adam: the ranks end bit-identical, and equal to the single-process step on all four images up to what a different batch
     size changes (other launch plans -> other fp32 summation orders -> a few bf16 roundings)."""
     plain, two = tmp_path / "plain.pt", tmp_path / "two.pt"
-    _run([CHILD, "plain", str(plain)], YOLO_AMD_SMALL_SPLIT=small_split)
+    env = {"YOLO_AMD_SMALL_SPLIT": small_split, "YOLO_AMD_PLAN_TABLE": small_split}
+    _run([CHILD, "plain", str(plain)], **env)
     port = 29900 + os.getpid() % 300 + 300 * int(small_split)
     _run(["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
-          CHILD, "gloo2", str(two)], timeout=900, YOLO_AMD_SMALL_SPLIT=small_split)
+          CHILD, "gloo2", str(two)], timeout=900, **env)
     a = torch.load(plain, weights_only=True)
     r0 = torch.load(str(two) + ".r0", weights_only=True)
     r1 = torch.load(str(two) + ".r1", weights_only=True)
@@ -76,8 +77,9 @@ def test_two_ranks_on_one_gpu_equal_the_single_process_step_on_the_whole_batch(t
         assert torch.equal(r0["grads"][n], r1["grads"][n]), n
     # mean of the two shard losses = loss of the whole batch (YOLOLoss divides by the local N, shards are equal)
     assert abs(0.5 * (r0["loss"] + r1["loss"]) - a["loss"]) <= 2e-3 * abs(a["loss"])
-    # small_split = "0" (config.SMALL_SPLIT off: every few-pixel layer is ONE plain launch at 2 and at 4 images -> the same fp32 summation orders):
-    # the plumbing is compared at the tolerance of a few bf16 roundings.  "1" (the default): the deep layers split their K range by the number
+    # small_split = "0" (config.SMALL_SPLIT and config.PLAN_TABLE off: every layer is ONE plain launch of the deterministic default plan at 2 and at 4
+    # images -> the same fp32 summation orders): the plumbing is compared at the tolerance of a few bf16 roundings.  "1" (the defaults: the shipped
+    # table has measured plans for batches 2 and 4, and problems without an entry split by rule): the deep layers split their K range by the number
     # of pixel tiles, so their fp32 sums are taken in another order at 2 and at 4 images -- 0.1-0.3 % of a gradient's norm at the head end of
     # the backward pass, growing to 1-2.6 % (cosine 0.975) at the first layers of this random-init LeakyReLU network, whose gates flip under a
     # rounding; the split itself is pinned against fp64 in test_gpu_layers.py::test_k_range_slabs_of_one_layer_equal_the_fp64_product

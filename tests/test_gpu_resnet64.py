@@ -87,7 +87,7 @@ def test_resnet_batch64_inference_and_nms(resnet_model):
 def test_resnet_batch64_head_gradients(resnet_model):
     """one batch-64 training step of the DetectionHead behind the frozen trunk (eval-mode trunk: BatchNorm folded, so the features of
     an image do not depend on the batch; dropout off): the loss equals the oracle's on the predictions, the head's gradients equal
-    the mean of the gradients of 8 batches of 8 (YOLOLoss divides by N) and a second run of the same step."""
+    a second run of the same step and -- for the same dL/dpred -- the mean of the gradients of 8 batches of 8 (YOLOLoss divides by N)."""
     from oracle import oracle as O
     from yolo import YOLOLoss
     g = copy.deepcopy(resnet_model).cuda().eval()
@@ -101,12 +101,15 @@ def test_resnet_batch64_head_gradients(resnet_model):
     crit = YOLOLoss()
     head_params = [(n, p) for n, p in g.head.named_parameters()]
 
-    def grads_of(xs, ts):
+    def grads_of(xs, ts, dpred=None):
         for _, p in head_params:
             p.grad = None
         pred = g(xs)
         loss, parts = crit(pred, ts)
-        loss.backward()
+        if dpred is None:
+            loss.backward()
+        else:
+            pred.backward(dpred)
         torch.cuda.synchronize()
         return pred.detach(), float(parts["total"]), {n: p.grad.detach().float().clone() for n, p in head_params}
 
@@ -115,14 +118,29 @@ def test_resnet_batch64_head_gradients(resnet_model):
     assert abs(total - ref5[0]) <= 1e-4 * max(1.0, abs(ref5[0]))
     _, total_b, g64b = grads_of(x, t)
     assert abs(total - total_b) <= 1e-6 * abs(total)
-    acc = None
+    # dL/dpred of the batch-64 pass, pushed through the sub-batches as well (teacher forcing).  Free-running sub-batches are NOT comparable: their
+    # predictions differ from the batch-64 ones by 0.2-0.8 % (other launch plans at batch 8 -> other fp32 summation orders), and on random-init
+    # predictions YOLOLoss's choice of the responsible box (arg-max of two IoUs that are both ~0, src/yolo/loss.py:110) turns that into a 2 % .. 65 %
+    # change of dL/dpred -- the same factor on EVERY layer's gradient, the last Linear included (tools/experiments/linearity_bisect.py); with the
+    # batch-64 dL/dpred the backward pass itself is compared, and its last Linear, behind no LeakyReLU gate, agrees to 0.1-0.5 %
+    leaf = pred.clone().requires_grad_(True)
+    l64, _ = crit(leaf, t)
+    l64.backward()
+    dpred = leaf.grad.detach()
+    _, _, g64_tf = grads_of(x, t, dpred)
+    acc, totals = None, []
     for i in range(0, 64, 8):
-        _, _, gi = grads_of(x[i:i + 8], t[i:i + 8])
+        _, ti, gi = grads_of(x[i:i + 8], t[i:i + 8], dpred[i:i + 8] * 8.0)        # (YOLOLoss divides by the local N)
+        totals.append(ti)
         acc = gi if acc is None else {n: acc[n] + gi[n] for n in acc}
+    assert abs(sum(totals) / 8 - total) <= 0.02 * abs(total), (totals, total)        # the loss VALUE is continuous in the predictions
     for n in g64:
         mean8 = acc[n] / 8
         assert torch.isfinite(g64[n]).all()
-        # rerun: equal up to the order of the weight-gradient kernels' fp32 atomics
+        # rerun: equal up to the order of the weight-gradient kernels' fp32 atomics; the teacher-forced pass runs the same launches
         assert _rel(g64b[n], g64[n]) < 1e-4, (n, _rel(g64b[n], g64[n]))
-        # linearity in the batch: other plans at batch 8 flip a few bf16 roundings / LeakyReLU gates of near-zero pre-activations
-        assert _rel(g64[n], mean8) < 0.03, (n, _rel(g64[n], mean8))
+        assert _rel(g64_tf[n], g64[n]) < 1e-4, (n, _rel(g64_tf[n], g64[n]))
+        # linearity in the batch: the batch-8 plans split the K range of the few-pixel layers (another fp32 summation order than at batch 64), which
+        # flips bf16 roundings and LeakyReLU gates of near-zero pre-activations -- 3-8 % on the gated layers of this random-init head (1 % when both
+        # batch sizes run plain launches), rounding level on the last Linear.  A wrong 1/N or a dropped sub-batch is >= 12 % there.
+        assert _rel(g64_tf[n], mean8) < (0.12 if "fc_layers.4" not in n else 0.01), (n, _rel(g64_tf[n], mean8))

@@ -22,6 +22,8 @@ class EngineConfig:
     AUTOTUNE: bool = False           # tools/tune_plans.py only: time the candidate plans of a problem without a table entry
     TILE_HINT: int = 0               # tests / tuning: force a tile configuration of yolo_igemm (0 = plan table; yolo_igemm_desc.tile_hint)
     TILE_PX: int = 0                 # with TILE_HINT: yolo_igemm_desc.tile_px of the forced configuration
+    PLAN_TABLE: bool = True          # read at import: load the measured plans of yolo/plans/gfx950.json (False, i.e. YOLO_AMD_PLAN_TABLE=0: every problem takes the deterministic
+                                     # default plan, whose fp32 summation order does not depend on the batch size unless SMALL_SPLIT splits K ranges)
     SMALL_SPLIT: bool = True         # problems without a table entry, < 2048 pixels under a deep K (small batches on the 14x14 / 7x7 maps): K ranges as slabs (False: one plain launch)
     PERSIST: bool = True             # plans with the persistent kernels (tile_hint 20 / 21) run them (False: the pipelined kernels 15 / 16 -- A/B runs)
     # ---- what is fused

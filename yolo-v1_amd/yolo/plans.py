@@ -375,5 +375,5 @@ def _tune_key(d: IgemmDesc):
     return (d.N, d.Ho, d.Wo, d.KH, d.KW, d.tap_len, d.Cout, d.stride, d.epilogue, 1 if d.pool2 == 3 else d.pool2, d.out_px_stride, d.in_px_stride)
 
 
-load_plans()
-
+if CFG.PLAN_TABLE:
+    load_plans()
