@@ -455,7 +455,7 @@ def main():
     small = None
     if rank == 0 and world == 1 and not a.no_nms:
         small = {"unit": "ms per forward (YOLOv1Backbone + FC head, inputs resident, back-to-back forwards)",
-                 "note": "yolo/plans/gfx950.json holds measured plans for batches 1, 16 and 64; few-pixel deep-K layers split their K range over the chip (DESIGN.md section 7)"}
+                 "note": "yolo/plans/gfx950.json holds measured plans for batches 1, 2, 4, 8, 16, 32 and 64; few-pixel deep-K layers split their K range over the chip (DESIGN.md section 7)"}
         model.eval()
         for nb in (1, 16):
             xb = x[:nb].contiguous()

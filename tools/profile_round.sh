@@ -6,6 +6,7 @@
 #   3. SQ counters (MFMA busy, LDS conflicts, issue stalls; two --pmc passes)   -> profiles/<tag>_igemm_sq_pmc.txt
 #   4. the same for the weight-gradient kernels over three training steps       -> profiles/<tag>_wgrad_traffic.json, <tag>_wgrad_pmc.txt
 #   5. kernel stats of the training step alone                                  -> profiles/<tag>_train_step_kernels.txt
+#   6. kernel stats of 200 single-image forwards                                -> profiles/<tag>_batch1_kernels.txt
 # Counter passes never run together with tracing (MI355X_MICROARCH.md, rocprofv3 PMC).
 set -e
 TAG=${1:-r2_v1}
@@ -30,3 +31,6 @@ cat profiles/${TAG}_wgrad_traffic.json
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT" -o train -- python3 tools/train_steps.py 10 > "$OUT/train.log" 2>&1
 python3 tools/kstats.py "$OUT"/train_kernel_stats.csv 40 > profiles/${TAG}_train_step_kernels.txt
 python3 bench.py > profiles/${TAG}_bench_unprofiled.json 2> /dev/null
+# 6. the single-image forward (predict.py; BASELINE configs[0] runs it on the CPU): kernel stats of 200 batch-1 forwards
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT" -o b1 -- python3 tools/small_batch_steps.py 200 1 > "$OUT/b1.log" 2>&1
+{ cat "$OUT/b1.log" | grep "ms per forward"; python3 tools/kstats.py "$OUT"/b1_kernel_stats.csv 30; } > profiles/${TAG}_batch1_kernels.txt
