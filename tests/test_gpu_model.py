@@ -593,6 +593,53 @@ def test_small_batches_unfuse_the_few_tile_pool_convs(model, n):
     assert _rel(out[True], out[False]) < 0.01, _rel(out[True], out[False])
 
 
+@pytest.mark.parametrize("n", [2, 4, 8, 32])
+def test_measured_plans_of_the_other_batch_sizes_agree_with_plain_launches(model, n):
+    """yolo/plans/gfx950.json holds measured plans for batches 2, 4, 8 and 32 as well (1, 16 and 64 have tests of their own).  The tuner only TIMES a
+    candidate; that each chosen plan also computes the layer is checked here for every problem of a batch size at once: forward and backward (a fixed
+    dL/dpred, so that YOLOLoss's discontinuity stays out) on the shipped plans against the same pass with no table entries and plain single launches.
+    A plan that drops or doubles a K range or a tile shows as an O(1) difference; other fp32 summation orders as 0.2-0.8 % of the predictions and a
+    few per cent of the gradients behind many LeakyReLU gates (rounding level on the last Linear)."""
+    import copy
+    from yolo import engine, plans
+    g = copy.deepcopy(model).cuda().train()
+    for mod in g.modules():
+        if isinstance(mod, torch.nn.Dropout):
+            mod.p = 0.0
+    torch.manual_seed(41)
+    x = torch.from_numpy(synth.synth_images(n, 17)).cuda()
+    dpred = torch.randn(n, 7, 7, 30, device="cuda") / n
+    shipped = dict(plans._TUNED)
+    assert sum(1 for k in shipped if k[0] == n) >= 60, "no measured plans for this batch size"
+    res = {}
+    try:
+        for name, table, split in (("shipped", shipped, True), ("plain", {}, False)):
+            plans._TUNED.clear()
+            plans._TUNED.update(table)
+            engine.SMALL_SPLIT = split
+            for p in g.parameters():
+                p.grad = None
+            pred = g(x)
+            pred.backward(dpred)
+            torch.cuda.synchronize()
+            res[name] = (pred.detach().float().clone(), {k: p.grad.detach().float().clone() for k, p in g.named_parameters()})
+            if name == "shipped":
+                used = [k for k in plans._TUNED if k[0] == n]
+                assert all(k in shipped for k in used), [k for k in used if k not in shipped]      # every problem of the step ran on a measured plan
+    finally:
+        plans._TUNED.clear()
+        plans._TUNED.update(shipped)
+        engine.SMALL_SPLIT = True
+    (pa, ga), (pb, gb) = res["shipped"], res["plain"]
+    assert _rel(pa, pb) < 0.02, _rel(pa, pb)
+    report = {k: round(_rel(ga[k], gb[k]), 4) for k in ga}
+    last = [k for k in report if k.startswith("head.4.")]
+    assert last and all(report[k] < 0.01 for k in last), report
+    # (2 images: 23-26 % at the first conv layers -- the same level as the two-rank test's cosine of 0.975 there; 4 .. 32 images: < 20 %.  A data-gradient
+    # plan that computes something else puts every layer in front of it at ~100 %)
+    assert max(report.values()) < (0.4 if n <= 2 else 0.2), report
+
+
 def test_gradient_arena_equals_autograd_path(model):
     """data-parallel plumbing on one GPU: with the gradient arena attached, backward writes the same
     gradients into the flat buffer, assigns p.grad views, and fires the bucket callbacks in arena order
