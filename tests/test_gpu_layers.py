@@ -414,6 +414,7 @@ def test_few_pixel_deep_k_layers_split_their_k_range(n, hw):
     res = {}
     for on in (True, False):
         engine.SMALL_SPLIT = on
+        engine.BORROW_PLANS = False          # the rule itself, not a plan measured for the same layer shape at another batch size
         saved = dict(plans._TUNED)
         try:
             for k in [k for k in plans._TUNED if k[0] == n and k[1] in (hw, ho)]:
@@ -427,6 +428,7 @@ def test_few_pixel_deep_k_layers_split_their_k_range(n, hw):
                 assert torch.equal(again[1], res[on][1]) and torch.equal(again[3][0], res[on][3][0])
         finally:
             engine.SMALL_SPLIT = True
+            engine.BORROW_PLANS = True
             plans._TUNED.clear()
             plans._TUNED.update(saved)
     yc, yg, gc, gg = res[True]

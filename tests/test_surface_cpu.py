@@ -412,6 +412,48 @@ def test_a_launch_with_batchnorm_statistics_gets_a_kernel_that_has_them(monkeypa
         assert 1 <= hint <= 14 and split <= 1 and b == 0 and e == 0, (plan, seen)
 
 
+def test_unmeasured_batch_sizes_borrow_the_nearest_measured_plan(monkeypatch):
+    """plans._borrowed_plan: nearest measured batch size by ratio (the larger one on a tie), same layer key otherwise; pixel-range forms, whose cut is a
+    pixel count, are not taken over; config.BORROW_PLANS / PLAN_TABLE switch it off; a plan the library refuses at the new size falls back to the rule."""
+    from yolo import plans
+    from yolo import _hip
+    from yolo.config import CONFIG
+    from yolo._hip import IgemmDesc
+    rest = (14, 14, 3, 3, 512, 1024, 1, 2, 0, 1024, 512)
+    table = {(8,) + rest: ("slabs", 4, 8, 0), (16,) + rest: ("tile", 20, 1, 196), (32,) + rest: (5, 1, 4096, 3), (64,) + rest: ("tile", 21, 1, 224),
+             (16, 7, 7) + rest[2:]: (11, 1)}
+    monkeypatch.setattr(plans, "_TUNED", dict(table))
+    monkeypatch.setattr(plans, "_BORROWED", set())
+    assert plans._borrowed_plan((13,) + rest) == ("tile", 20, 1, 196)          # 16 (x1.23) before 8 (x1.63)
+    assert plans._borrowed_plan((11,) + rest) == ("slabs", 4, 8, 0)            # 8 (x1.375) before 16 (x1.45)
+    assert plans._borrowed_plan((12,) + rest) == ("tile", 20, 1, 196)          # 16 (x1.33) before 8 (x1.5)
+    assert plans._borrowed_plan((128,) + rest) == ("tile", 21, 1, 224)
+    assert plans._borrowed_plan((6,) + rest) is None                            # below 8 images: the default rule sizes its K ranges by the pixel count
+    assert plans._borrowed_plan((30,) + rest) is None                           # nearest is 32, a pixel-range form
+    assert plans._borrowed_plan((13, 28, 28) + rest[2:]) is None                # no such layer at any batch size
+    monkeypatch.setattr(CONFIG, "BORROW_PLANS", False)
+    assert plans._borrowed_plan((13,) + rest) is None
+    monkeypatch.setattr(CONFIG, "BORROW_PLANS", True)
+    # igemm_call: the borrowed plan runs once under a guard; refused -> the default rule takes the key for good
+    d = IgemmDesc()
+    d.N, d.Ho, d.Wo, d.KH, d.KW, d.tap_len, d.Cout, d.stride, d.epilogue, d.pool2, d.out_px_stride, d.in_px_stride = (13,) + rest
+    d.split_k = 1
+    calls = []
+
+    def fake(L_, dd, plan, *a):
+        calls.append(plan)
+        if plan == ("tile", 20, 1, 196):
+            raise _hip.HipUnsupported("refused")
+
+    monkeypatch.setattr(plans, "_run_plan_igemm", fake)
+    monkeypatch.setattr(plans.RT, "lib", lambda: None)
+    plans.igemm_call(d, None, None, None, None, None, None, "test")
+    assert calls[0] == ("tile", 20, 1, 196) and len(calls) == 2 and calls[1] == plans._default_plan(d)
+    assert plans._TUNED[(13,) + rest] == calls[1] and not plans._BORROWED
+    plans.igemm_call(d, None, None, None, None, None, None, "test")
+    assert len(calls) == 3 and calls[2] == calls[1]
+
+
 def test_shipped_plan_table_and_weight_gradient_choices(tmp_path):
     """yolo/plans/gfx950.json: every entry parses into a plan the engine knows, the "wgrad" section (kernel choices measured inside the
     training step, tools/search_wgrad.py) reaches Plan._wgrad_desc, and save_plans / load_plans round-trip both sections."""

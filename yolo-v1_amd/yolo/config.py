@@ -24,6 +24,8 @@ class EngineConfig:
     TILE_PX: int = 0                 # with TILE_HINT: yolo_igemm_desc.tile_px of the forced configuration
     PLAN_TABLE: bool = True          # read at import: load the measured plans of yolo/plans/gfx950.json (False, i.e. YOLO_AMD_PLAN_TABLE=0: every problem takes the deterministic
                                      # default plan, whose fp32 summation order does not depend on the batch size unless SMALL_SPLIT splits K ranges)
+    BORROW_PLANS: bool = True        # a problem of a batch size without measured plans (a DataLoader's ragged last batch, a user's own batch size) runs the plan measured
+                                     # for the same layer at the nearest measured batch size (plans._borrowed_plan) instead of the default rule
     SMALL_SPLIT: bool = True         # problems without a table entry, < 2048 pixels under a deep K (small batches on the 14x14 / 7x7 maps): K ranges as slabs (False: one plain launch)
     PERSIST: bool = True             # plans with the persistent kernels (tile_hint 20 / 21) run them (False: the pipelined kernels 15 / 16 -- A/B runs)
     # ---- what is fused

@@ -150,6 +150,27 @@ def _default_plan(d: IgemmDesc):
     return best
 
 
+_BORROWED = set()       # keys whose plan in _TUNED was taken over from another batch size and has not run yet (igemm_call falls back to the default if the library refuses it)
+
+
+def _borrowed_plan(key):
+    """the plan measured for the same layer (every key field but N equal) at the nearest measured batch size, nearest by ratio, the larger one on a tie.
+    Launch plans name a kernel configuration, a tile size, a K-range count -- nothing that depends on the number of pixels -- except the pixel-range
+    forms (hint, order, cut, hint2), whose cut is a pixel count: those are not taken over.  tools/batch_sweep.py, YOLOv1 / ResNet-50 variant forward: batch 13
+    1.154 -> 1.027 / 2.096 -> 1.892 ms, 24 1.482 -> 1.456 / 3.052 -> 2.673, 48 2.452 -> 2.286 / 5.119 -> 4.427."""
+    n = key[0]
+    if not (CFG.BORROW_PLANS and CFG.PLAN_TABLE) or n < 8:      # (below 8 images the default rule, which sizes its K ranges by the actual pixel count, measured 1-3 % faster)
+        return None
+    sizes = sorted({k[0] for k in _TUNED if k[1:] == key[1:] and k not in _BORROWED and k[0] != n})
+    if not sizes:
+        return None
+    nb = min(sizes, key=lambda b: (max(b, n) / min(b, n), -b))
+    plan = _TUNED[(nb,) + tuple(key[1:])]
+    if isinstance(plan[0], int) and len(plan) == 4:
+        return None
+    return plan
+
+
 def _run_plan_igemm(L_, d: IgemmDesc, plan, inp, w, bias, aux, out, st, what):
     """run one yolo_igemm problem with a launch plan (forms: see above)"""
     if d.bn_stats and (plan[0] in ("splitk", "slabs") or (isinstance(plan[0], int) and len(plan) == 4)):
@@ -357,8 +378,20 @@ def igemm_call(d: IgemmDesc, inp, w, bias, aux, out, st, what: str):
         if CFG.AUTOTUNE and CFG.TIMERS is None and (d.N * d.Ho * d.Wo >= 2048 or d.KH * d.KW * d.tap_len * d.Cout >= (1 << 20)):
             best = _tune(L_, d, inp, w, bias, aux, out, st, what)
         else:
-            best = _default_plan(d)
+            best = _borrowed_plan(key)
+            if best is not None:
+                _BORROWED.add(key)
+            else:
+                best = _default_plan(d)
         _TUNED[key] = best
+    if key in _BORROWED:
+        # first run of a plan measured at another batch size: if the library refuses it for this pixel count (it checks before it launches), the default rule
+        _BORROWED.discard(key)
+        try:
+            _run_plan_igemm(L_, d, best, inp, w, bias, aux, out, st, what)
+            return
+        except _hip.HipUnsupported:
+            best = _TUNED[key] = _default_plan(d)
     rec = CFG.PLAN_TIMES
     if rec is None:
         _run_plan_igemm(L_, d, best, inp, w, bias, aux, out, st, what)
