@@ -39,6 +39,7 @@ class Layer:
     pad: int = 0
     lrelu: bool = False
     dropout: float = 0.0
+    drop_mod: object = None     # the nn.Dropout behind a Linear: its p is read at every forward, as stock torch does (a plan outlives `model.head[3].p = 0.0`)
     weight: nn.Parameter | None = None
     bias: nn.Parameter | None = None
     first: bool = False            # the 3-channel 7x7/s2 stem (NHWC4 input, row-segment taps)
@@ -163,11 +164,11 @@ class Plan:
                     raise ValueError(f"unsupported Linear {m}: in_features must be a multiple of 64")
                 act = isinstance(nxt, nn.LeakyReLU)
                 j = i + (2 if act else 1)
-                drop = 0.0
+                drop, drop_mod = 0.0, None
                 if j < len(mods) and isinstance(mods[j], nn.Dropout):
-                    drop = mods[j].p
+                    drop, drop_mod = mods[j].p, mods[j]
                     j += 1
-                layers.append(Layer("fc", Cout=m.out_features, Cin=m.in_features, lrelu=act, dropout=drop, weight=m.weight, bias=m.bias))
+                layers.append(Layer("fc", Cout=m.out_features, Cin=m.in_features, lrelu=act, dropout=drop, drop_mod=drop_mod, weight=m.weight, bias=m.bias))
                 i = j
             else:
                 raise ValueError(f"unsupported module in plan: {m}")
@@ -584,10 +585,12 @@ class Plan:
                         check(L_.yolo_cast_f32_to_bf16(ptr(yf), yf.numel(), ptr(yb), st), "cast")
                 mask = None
                 y_act = yb
+                if L.drop_mod is not None:
+                    L.dropout = float(L.drop_mod.p)          # (the backward of this forward reads L.dropout)
                 if not last and L.dropout > 0 and drop_training:
                     mask = (torch.rand((N, L.Cout), device=dev) >= L.dropout).to(torch.uint8)
                     yd = torch.empty_like(yb)
-                    check(L_.yolo_dropout_bf16(ptr(yb), ptr(mask), 1.0 / (1.0 - L.dropout), yb.numel(), ptr(yd), st), "dropout")
+                    check(L_.yolo_dropout_bf16(ptr(yb), ptr(mask), 1.0 / max(1.0 - L.dropout, 1e-12) if L.dropout < 1.0 else 0.0, yb.numel(), ptr(yd), st), "dropout")
                     cur = yd
                 else:
                     cur = yb
@@ -765,7 +768,7 @@ class Plan:
                 ldg = _round_up(L.Cout, 32)
                 gb = torch.empty((N, ldg), dtype=torch.bfloat16, device=dev)
                 # through dropout + LeakyReLU of THIS layer's output (none for the last layer)
-                check(L_.yolo_scale_rows_to_bf16(ptr(g_flat), ptr(mask), (1.0 / (1.0 - L.dropout)) if mask is not None else 1.0,
+                check(L_.yolo_scale_rows_to_bf16(ptr(g_flat), ptr(mask), ((1.0 / (1.0 - L.dropout)) if L.dropout < 1.0 else 0.0) if mask is not None else 1.0,
                                                  ptr(y_act) if (L.lrelu and not last) else None, self.SLOPE, N, L.Cout, ldg, ptr(gb), st), "scale_rows")
                 # weight / bias gradient, native [O][K] layout
                 dw, db = grad_tensors(li)
