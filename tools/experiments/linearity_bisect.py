@@ -1,5 +1,6 @@
 """tests/test_gpu_resnet64.py::test_resnet_batch64_head_gradients taken apart: gradients of the DetectionHead behind the frozen ResNet trunk at batch 64
-against the mean over eight batches of 8, with the batch-8 problems on (a) the shipped plans, (b) the default rules, (c) plain launches -- and how far the
+against the mean over eight batches of 8, with the batch-8 problems on (a) the shipped plans, (b) no batch-8 entries (plans borrowed from the neighbouring batch sizes, else the default rule; when this was
+written: the default rule), (c) plain launches -- and how far the
 PREDICTIONS of the sub-batches are from the batch-64 ones, since YOLOLoss's responsible-box choice turns a rounding of a prediction into a
 different gradient."""
 import os, sys
@@ -48,7 +49,7 @@ dpred64 = pred64.grad.detach().clone()
 p64, g64 = grads_of(x, t)
 _, g64_tf = grads_of(x, t, dpred64)
 print("batch 64: loss path vs teacher-forced path:", {n: round(rel(g64_tf[n], g64[n]), 5) for n in ("fc_layers.4.weight", "conv_layers.0.weight")})
-for name, table, split in (("shipped", shipped, True), ("default rules", {k: v for k, v in shipped.items() if k[0] != 8}, True),
+for name, table, split in (("shipped", shipped, True), ("no batch-8 entries (borrowed from batch 16 / 4, else the rule)", {k: v for k, v in shipped.items() if k[0] != 8}, True),
                            ("plain", {k: v for k, v in shipped.items() if k[0] != 8}, False)):
     P._TUNED.clear(); P._TUNED.update(table); engine.SMALL_SPLIT = split
     acc = acc_tf = None
