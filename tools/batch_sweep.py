@@ -1,10 +1,10 @@
 #!/usr/bin/env python3
 """Forward time of YOLOv1 (and of the ResNet-50 variant) at the batch sizes the shipped entry points use: 1 (predict.py), 16 (evaluate.py's
-default), 32, 64 (the benchmarked size) and a ragged 13 (the last batch of a DataLoader without drop_last: no measured plans, the
-deterministic default).  Prints a markdown table: ms per batch, images/s, TFLOP/s, per-image time relative to batch 64, and how many of
-the batch's yolo_igemm problems ran on a measured plan of yolo/plans/gfx950.json.
+default), 32, 64 (the benchmarked size) and a ragged 13 (the last batch of a DataLoader without drop_last: no measured plans -- borrowed from
+batch 16, plans._borrowed_plan).  Prints a markdown table: ms per batch, images/s, TFLOP/s, per-image time relative to the LAST batch size of the
+list, and how many of the batch's yolo_igemm problems ran on a measured plan of yolo/plans/gfx950.json.
 
-    python tools/batch_sweep.py [--resnet]"""
+    [BATCHES=1,2,4,8,13,16,32,64] [NO_SMALL_SPLIT=1] [YOLO_AMD_BORROW_PLANS=0] python tools/batch_sweep.py [--resnet]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "yolo-v1_amd"))
