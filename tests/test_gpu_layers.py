@@ -396,6 +396,52 @@ def test_fc_dgrad_behind_flatten_matches_cpu():
         _close(a, b, 3.0, n, frac=0.01)
 
 
+def test_tuner_drops_a_candidate_that_computes_something_else(monkeypatch):
+    """tools/tune_plans.py's path (config.AUTOTUNE): the tuner times the candidate plans of a problem and, before the fastest enters the table, compares
+    its output buffer with the default plan's.  Here every candidate but the default plan is made to leave zeros behind: whatever their times, the
+    default plan must be the one that is kept, and it must reproduce the un-sabotaged result."""
+    from yolo import engine, plans
+    torch.manual_seed(21)
+    conv = nn.Conv2d(128, 256, 3, 1, 1).cuda()
+    x = torch.randn(4, 128, 28, 28, device="cuda")
+    saved = dict(plans._TUNED)
+    real_run = plans._run_plan_igemm
+    sabotaged, default = [], []
+
+    def run(L_, d, plan, inp, w, bias, aux, out, st, what):
+        real_run(L_, d, plan, inp, w, bias, aux, out, st, what)
+        default.append(plans._default_plan(d))
+        if sabotaged and plan != default[-1]:
+            torch.cuda.synchronize()
+            addr = out.value if hasattr(out, "value") else int(out)
+            torch.as_tensor(plans._RawDevice(addr, d.N * d.out_img_stride, False), device="cuda").zero_()
+
+    try:
+        plans._TUNED.clear()
+        engine.AUTOTUNE, engine.TUNE_LOG = True, []
+        with torch.no_grad():
+            ref = engine.run_plan(engine.Plan.from_modules([conv, nn.LeakyReLU(0.1)], 128, False), x, False).float().clone()
+        (key, winner, top), = engine.TUNE_LOG
+        assert plans._TUNED[key] == winner and top[0][0] == winner
+        # again, with every candidate but the default plan sabotaged
+        plans._TUNED.clear()
+        engine.TUNE_LOG = []
+        sabotaged.append(winner)
+        monkeypatch.setattr(plans, "_run_plan_igemm", run)
+        with torch.no_grad():
+            plan2 = engine.Plan.from_modules([conv, nn.LeakyReLU(0.1)], 128, False)
+            engine.run_plan(plan2, x, False)
+            monkeypatch.setattr(plans, "_run_plan_igemm", real_run)
+            got = engine.run_plan(plan2, x, False).float()
+        (key2, winner2, _), = engine.TUNE_LOG
+        assert key2 == key and winner2 == default[-1] and plans._TUNED[key] == winner2
+        _close(got, ref, 2.0, "the kept plan")
+    finally:
+        engine.AUTOTUNE, engine.TUNE_LOG = False, None
+        plans._TUNED.clear()
+        plans._TUNED.update(saved)
+
+
 @pytest.mark.parametrize("n,hw", [(1, 14), (2, 14), (1, 7), (4, 7), (3, 9)])
 def test_few_pixel_deep_k_layers_split_their_k_range(n, hw):
     """small batches on the 14x14 / 7x7 maps: a problem without a table entry and < 2048 pixels under K >= 2304 runs as K ranges stored as slabs
